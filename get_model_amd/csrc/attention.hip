@@ -1,0 +1,483 @@
+// Fused (flash-style) multi-head attention for the GET region encoder on gfx950, head_dim 64.
+//
+// Replaces model/transformer.py:58-96 of the reference (reshape/permute, q*scale, q@k^T, softmax, attn@v,
+// transpose) and its autograd backward.  Input is the packed projection qkv[B,T,3,H,64] (bf16) exactly as
+// the QKV GEMM writes it; output is o[B,T,H*64] (bf16) plus the per-row logsumexp [B,H,T] (fp32, natural
+// log) that the backward uses to recompute probabilities.  The [B,H,T,T] score tensor never exists.
+//
+// forward  : one workgroup = 4 waves = 128 query rows of one (b,h); K/V stream through LDS in 64-key chunks
+//            (16-B global_load_lds, swizzled image, double buffered).  "Query on the lane": S^T = K.Q^T so
+//            each lane owns one query column -> online softmax is lane-local (+1 exchange with lane^32),
+//            and the P^T accumulator feeds the PV MFMA as its B operand without leaving registers.
+// backward : one workgroup = 8 waves = 256 keys of one (b,h) (wave w owns 32 keys; dK^T, dV^T stay in its
+//            accumulators for the whole sweep over 32-row query slices).  "Key on the lane": S = Q.K^T and
+//            dP = dO.V^T accumulators are the B operands of dV^T += dO^T.P and dK^T += Q^T.dS; only dS
+//            crosses LDS (transposed image) for dQ = dS.K, which the 8 waves compute as eight 16x16 tiles
+//            over all 256 keys -> no cross-wave or cross-workgroup reduction when T <= 256 (fp32 atomics
+//            into dq_acc otherwise).
+#include "common.h"
+
+#define HD 64
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// chunk swizzle for images with 128-byte rows (64 bf16): serves both ds_read_b128 row reads (16-lane groups
+// see 8 distinct values per row parity) and ds_read_b64_tr_b16 transposed reads (rows r, r+2 land in
+// different 64-B halves).
+__device__ __forceinline__ int swz128(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x >> 1);
+}
+// byte offset of element column `col` (multiple of 4) of row `row` in a 128-B-row swizzled image
+__device__ __forceinline__ int off128(int row, int col) {
+    return row * 128 + ((((col >> 3) ^ swz128(row)) << 4) | ((col & 4) << 1));
+}
+__device__ __forceinline__ s16x4 lds_tr16a(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join_tr_a(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                        float a7) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = {pack2bf(a0, a1), pack2bf(a2, a3), pack2bf(a4, a5), pack2bf(a6, a7)};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+struct AttnFwdArgs {
+    const bf16_t* qkv;
+    bf16_t* out;
+    float* lse;
+    int B, T, H;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];   // [buf][K|V][64 keys][128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, H = p.H;
+    const int nqb = (T + 127) >> 7;
+    const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+    const int b = bh / H, h = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;   // elements per token row of qkv
+    const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
+    const int q0 = qb * 128 + wave * 32;
+    const int r = lane & 31, h2 = lane >> 5;
+
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, T - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * rs + kk * 16 + h2 * 8);
+    }
+
+    const int nchunk = (T + 63) >> 6;
+    // staging: K chunk = 8 wave-instructions (8 rows x 128 B each); 2 per wave, same for V
+    auto stage = [&](int buf, int c) {
+        char* kb = smem + buf * 16384;
+        char* vb = kb + 8192;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int I = wave * 2 + j;
+            const int row = I * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz128(row);
+            const int key = min(c * 64 + row, T - 1);
+            const bf16_t* src = base + (size_t)key * rs + chunk * 8;
+            glds16(src + H * HD, kb + I * 1024);
+            glds16(src + 2 * H * HD, vb + I * 1024);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const float c2 = p.scale * LOG2E;
+    const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) stage(cur ^ 1, c + 1);
+        const char* kb = smem + cur * 16384;
+        const char* vb = kb + 8192;
+        if (q0 < T) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int key0 = c * 64 + sub * 32;
+                if (key0 < T) {
+                    f32x16 s;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int row = sub * 32 + r;
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(
+                            kb + row * 128 + (((2 * kk + h2) ^ swz128(row)) << 4));
+                        s = MFMA32(kf, qf[kk], s);
+                    }
+                    float mloc = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                        s[i] = (key < T) ? s[i] * c2 : -INFINITY;
+                        mloc = fmaxf(mloc, s[i]);
+                    }
+                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                    const float mnew = fmaxf(m, mloc);
+                    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                    float lsum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s[i] = __builtin_amdgcn_exp2f(s[i] - mnew);
+                        lsum += s[i];
+                    }
+                    l = l * alpha + lsum;
+                    m = mnew;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                    bf16x8 pf[2];
+                    pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+                    pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int ss = 0; ss < 2; ++ss) {
+                            const int klo = sub * 32 + 16 * ss + 4 * h2 + qq;
+                            const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
+                            const bf16x8 vf = join_tr_a(lds_tr16a(vb + off128(klo, col)),
+                                                        lds_tr16a(vb + off128(klo + 8, col)));
+                            o[db] = MFMA32(vf, pf[ss], o[db]);
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + r;
+    if (q < T) {
+        const float inv = 1.0f / l;
+        bf16_t* orow = p.out + ((size_t)b * T + q) * (H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + 8 * g4 + 4 * h2;
+                *reinterpret_cast<uint2*>(orow + d0) = pack4bf(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
+                                                               o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+            }
+        if (h2 == 0) p.lse[((size_t)b * H + h) * T + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+    }
+}
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                  float* __restrict__ delta, int B, int T, int H) {
+    const size_t n = (size_t)B * T * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % H);
+        const size_t bt = i / H;
+        const int t = (int)(bt % T);
+        const size_t b = bt / T;
+        const uint4* po = reinterpret_cast<const uint4*>(o + i * HD);
+        const uint4* pd = reinterpret_cast<const uint4*>(dout + i * HD);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint4 a = po[k], d = pd[k];
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                acc += bf2f(aw[w] & 0xffff) * bf2f(dw[w] & 0xffff) + bf2f(aw[w] >> 16) * bf2f(dw[w] >> 16);
+        }
+        delta[(b * H + h) * T + t] = acc;
+    }
+}
+
+struct AttnBwdArgs {
+    const bf16_t* qkv;
+    const bf16_t* dout;   // [B,T,H*64]
+    const float* lse;     // [B,H,T]
+    const float* delta;   // [B,H,T]
+    bf16_t* dqkv;         // [B,T,3,H,64]
+    float* dq_acc;        // [B,T,H,64] fp32, only when T > 256
+    int B, T, H;
+    float scale;
+};
+
+// LDS map (bytes)
+#define BW_KIMG 0                 // [256 keys][128 B]
+#define BW_QD 32768               // 2 x (Q slice 4 KB | dO slice 4 KB)
+#define BW_DS 49152               // [256 keys][32 q] bf16 (64-B rows, halves swapped by (key>>3)&1)
+#define BW_ST 65536               // 2 x (lse'[32] | delta[32]) fp32
+#define BW_LDS (65536 + 512)
+
+__global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, H = p.H;
+    const int nkb = (T + 255) >> 8;
+    const int bh = blockIdx.x / nkb, kbi = blockIdx.x - bh * nkb;
+    const int b = bh / H, h = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;
+    const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
+    const bf16_t* dobase = p.dout + (size_t)b * T * (H * HD) + h * HD;
+    const float* lse = p.lse + ((size_t)b * H + h) * T;
+    const float* delta = p.delta + ((size_t)b * H + h) * T;
+    const int key_base = kbi * 256;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int mykey = key_base + wave * 32 + r;          // this lane's key (column of S, dP)
+    const bool wave_active = (key_base + wave * 32) < T;  // wave-uniform
+    const float c2 = p.scale * LOG2E;
+    const float inv_scale = 1.0f / p.scale;
+
+    // ---- K image: 256 rows = 32 wave-instructions, 4 per wave ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int I = wave * 4 + j;
+        const int row = I * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz128(row);
+        const int key = min(key_base + row, T - 1);
+        glds16(base + (size_t)key * rs + H * HD + chunk * 8, smem + BW_KIMG + I * 1024);
+    }
+    // ---- V fragments of this wave's 32 keys (second operand of dP = dO.V^T): V[key r][16kk + 8h2 ..] ----
+    bf16x8 vf[4];
+    {
+        const int key = min(mykey, T - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            vf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * rs + 2 * H * HD + kk * 16 + h2 * 8);
+    }
+
+    const int nslice = (T + 31) >> 5;
+    auto stage = [&](int buf, int sl) {
+        // Q slice: waves 0-3, dO slice: waves 4-7; 8 rows (1 KiB) per wave-instruction
+        const int w4 = wave & 3;
+        const int row = w4 * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz128(row);
+        const int q = min(sl * 32 + row, T - 1);
+        char* dst = smem + BW_QD + buf * 8192 + (wave >> 2) * 4096 + w4 * 1024;
+        const bf16_t* src = (wave < 4) ? (base + (size_t)q * rs + chunk * 8)
+                                       : (dobase + (size_t)q * (H * HD) + chunk * 8);
+        glds16(src, dst);
+        if (tid < 64) {
+            const int qi = sl * 32 + (tid & 31);
+            float v;
+            if (tid < 32) v = (qi < T) ? lse[qi] * inv_scale : INFINITY;
+            else v = (qi < T) ? delta[qi] : 0.f;
+            reinterpret_cast<float*>(smem + BW_ST + buf * 256)[tid] = v;
+        }
+    };
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    stage(0, 0);
+    __syncthreads();
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int cur = sl & 1;
+        if (sl + 1 < nslice) stage(cur ^ 1, sl + 1);
+        const char* qimg = smem + BW_QD + cur * 8192;
+        const char* doimg = qimg + 4096;
+        const float* st = reinterpret_cast<const float*>(smem + BW_ST + cur * 256);
+        if (wave_active) {
+            // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2
+            f32x16 s, dp;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 a = *reinterpret_cast<const float4*>(st + 8 * g4 + 4 * h2);
+                const float4 d = *reinterpret_cast<const float4*>(st + 32 + 8 * g4 + 4 * h2);
+                s[4 * g4] = -a.x; s[4 * g4 + 1] = -a.y; s[4 * g4 + 2] = -a.z; s[4 * g4 + 3] = -a.w;
+                dp[4 * g4] = -d.x; dp[4 * g4 + 1] = -d.y; dp[4 * g4 + 2] = -d.z; dp[4 * g4 + 3] = -d.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int ch = ((2 * kk + h2) ^ swz128(r)) << 4;
+                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(qimg + r * 128 + ch);
+                const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(doimg + r * 128 + ch);
+                const int krow = wave * 32 + r;
+                const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(
+                    smem + BW_KIMG + krow * 128 + (((2 * kk + h2) ^ swz128(krow)) << 4));
+                s = MFMA32(qfr, kfr, s);      // S'[q][key] = Q.K^T - lse/scale
+                dp = MFMA32(dofr, vf[kk], dp);  // dP'[q][key] = dO.V^T - delta
+            }
+            const bool kvalid = mykey < T;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pr = kvalid ? __builtin_amdgcn_exp2f(s[i] * c2) : 0.f;
+                s[i] = pr;                       // P
+                dp[i] = pr * dp[i] * p.scale;    // dS (already scaled for dQ / dK)
+            }
+            bf16x8 pf[2], dsf[2];
+            pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+            pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+            dsf[0] = pack8(dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[7]);
+            dsf[1] = pack8(dp[8], dp[9], dp[10], dp[11], dp[12], dp[13], dp[14], dp[15]);
+            // dV^T[d][key] += dO^T[d][q].P[q][key] ; dK^T[d][key] += Q^T[d][q].dS[q][key]
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const int qlo = 16 * ss + 4 * h2 + qq;
+                    const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
+                    const bf16x8 dot = join_tr_a(lds_tr16a(doimg + off128(qlo, col)),
+                                                 lds_tr16a(doimg + off128(qlo + 8, col)));
+                    const bf16x8 qt = join_tr_a(lds_tr16a(qimg + off128(qlo, col)),
+                                                lds_tr16a(qimg + off128(qlo + 8, col)));
+                    dv[db] = MFMA32(dot, pf[ss], dv[db]);
+                    dk[db] = MFMA32(qt, dsf[ss], dk[db]);
+                }
+            // dS^T image: row = key (wave*32 + r), 32 q per row (64 B); 32-B halves swapped when (key>>3)&1
+            {
+                const int krow = wave * 32 + r;
+                char* row = smem + BW_DS + krow * 64;
+                const int hs = (krow >> 3) & 1;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int q = 8 * g4 + 4 * h2;   // first of 4 consecutive query rows
+                    const int byte = ((((q >> 4) ^ hs) << 5) | ((q & 15) << 1));
+                    *reinterpret_cast<uint2*>(row + byte) =
+                        pack4bf(dp[4 * g4], dp[4 * g4 + 1], dp[4 * g4 + 2], dp[4 * g4 + 3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys ----
+        {
+            const int qh = wave & 1, dblk = wave >> 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int nks = min(8, (T - key_base + 31) >> 5);
+            for (int ks = 0; ks < nks; ++ks) {
+                const int klo = ks * 32 + 8 * gi + qq;
+                const int khi = klo + 4;
+                const int kcol = dblk * 16 + 4 * pp;
+                const bf16x8 kt = join_tr_a(lds_tr16a(smem + BW_KIMG + off128(klo, kcol)),
+                                            lds_tr16a(smem + BW_KIMG + off128(khi, kcol)));
+                const int qcol = 4 * pp;   // within the 16-query half
+                const int blo = klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | (qcol << 1));
+                const int bhi = khi * 64 + ((((qh ^ ((khi >> 3) & 1)) << 5)) | (qcol << 1));
+                const bf16x8 dst = join_tr_a(lds_tr16a(smem + BW_DS + blo), lds_tr16a(smem + BW_DS + bhi));
+                acc = MFMA16(kt, dst, acc);   // D[d][q] = sum_key K[key][d] dS[q][key]
+            }
+            const int q = sl * 32 + qh * 16 + (lane & 15);
+            const int d0 = dblk * 16 + (lane >> 4) * 4;
+            if (q < T) {
+                if (p.dq_acc == nullptr) {
+                    *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
+                        pack4bf(acc[0], acc[1], acc[2], acc[3]);
+                } else {
+                    float* dst = p.dq_acc + (((size_t)b * T + q) * H + h) * HD + d0;
+                    atomicAdd(dst, acc[0]); atomicAdd(dst + 1, acc[1]);
+                    atomicAdd(dst + 2, acc[2]); atomicAdd(dst + 3, acc[3]);
+                }
+            }
+        }
+        // the next iteration's first barrier (after its S/dP phase) orders the dS image reuse: writes of
+        // iteration sl+1 happen only after every wave has left this dQ phase?  No -- waves are free to run
+        // ahead, so fence here.
+        __syncthreads();
+    }
+
+    if (mykey < T) {
+        bf16_t* krow = p.dqkv + ((size_t)b * T + mykey) * rs + H * HD + h * HD;
+        bf16_t* vrow = krow + H * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + 8 * g4 + 4 * h2;
+                *reinterpret_cast<uint2*>(krow + d0) =
+                    pack4bf(dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(vrow + d0) =
+                    pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
+            }
+    }
+}
+
+// dqkv[b,t,0,h,:] = bf16(dq_acc[b,t,h,:])   (long-context path only)
+__global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dqkv, size_t ntok,
+                                       int H) {
+    const size_t n4 = ntok * H * (HD / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t tok = i / (H * (HD / 4));
+        const int rem = (int)(i - tok * (H * (HD / 4)));
+        const float4 v = *reinterpret_cast<const float4*>(acc + i * 4);
+        *reinterpret_cast<uint2*>(dqkv + tok * (size_t)(3 * H * HD) + rem * 4) = pack4bf(v.x, v.y, v.z, v.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale,
+                        hipStream_t st) {
+    GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_fwd: bad shape B=%d T=%d H=%d", B, T, H);
+    GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "attn_fwd: pointers must be 16-byte aligned");
+    AttnFwdArgs a{qkv, out, lse, B, T, H, scale};
+    const int nqb = (T + 127) / 128;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H * nqb), dim3(256), 0, st, a);
+    GETMI_CHECK_LAUNCH("attn_fwd");
+    return GETMI_OK;
+}
+
+size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
+    size_t n = (size_t)B * H * T * sizeof(float);                       // delta
+    n = (n + 255) & ~(size_t)255;
+    if (T > 256) n += (size_t)B * T * H * HD * sizeof(float);           // dq_acc
+    return n;
+}
+
+int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
+                        int B, int T, int H, float scale, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
+    GETMI_CHECK_ARG(workspace_bytes >= getmi_attn_bwd_workspace_bytes(B, T, H), "attn_bwd: workspace too small");
+    GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
+                        ((uintptr_t)out % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
+                    "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
+    float* delta = reinterpret_cast<float*>(workspace);
+    float* dq_acc = nullptr;
+    if (T > 256) {
+        size_t off = ((size_t)B * H * T * sizeof(float) + 255) & ~(size_t)255;
+        dq_acc = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + off);
+        if (hipMemsetAsync(dq_acc, 0, (size_t)B * T * H * HD * sizeof(float), st) != hipSuccess) {
+            getmi_set_error("attn_bwd: memset failed");
+            return GETMI_ERR_LAUNCH;
+        }
+    }
+    {
+        const size_t n = (size_t)B * T * H;
+        int grid = (int)((n + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, st, out, dout, delta, B, T, H);
+        GETMI_CHECK_LAUNCH("attn_delta");
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS);
+        attr_set = true;
+    }
+    AttnBwdArgs a{qkv, dout, lse, delta, dqkv, dq_acc, B, T, H, scale};
+    const int nkb = (T + 255) / 256;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
+    GETMI_CHECK_LAUNCH("attn_bwd");
+    if (dq_acc) {
+        const size_t n4 = (size_t)B * T * H * (HD / 4);
+        int grid = (int)((n4 + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(attn_dq_convert_kernel, dim3(grid), dim3(256), 0, st, dq_acc, dqkv, (size_t)B * T, H);
+        GETMI_CHECK_LAUNCH("attn_dq_convert");
+    }
+    return GETMI_OK;
+}

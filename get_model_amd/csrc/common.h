@@ -1,0 +1,79 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the GET region hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __bfloat16_as_ushort(__float2bfloat16(f)); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ uint2 pack4bf(float a, float b, float c, float d) {
+    return make_uint2(pack2bf(a, b), pack2bf(c, d));
+}
+
+// 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4). LDS destination = lds_wave_base +
+// lane*16 (wave-uniform base), global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (bid % 8 equal) get a
+// contiguous range of logical ids, so neighbouring tiles hit the same per-XCD L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative, fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- host side error channel (thread-local message, C-ABI returns an int code) ----
+void getmi_set_error(const char* fmt, ...);
+#define GETMI_OK 0
+#define GETMI_ERR_ARG 1
+#define GETMI_ERR_LAUNCH 2
+
+#define GETMI_CHECK_ARG(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            getmi_set_error(__VA_ARGS__);          \
+            return GETMI_ERR_ARG;                  \
+        }                                          \
+    } while (0)
+
+#define GETMI_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            getmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+            return GETMI_ERR_LAUNCH;                                                     \
+        }                                                                                \
+    } while (0)

@@ -1,0 +1,419 @@
+// bf16 MFMA GEMMs for gfx950 (MI355X).
+//
+//   gemm_tn : C[M,N] = A[M,K] * B[N,K]^T      (both operands K-contiguous)  -- forward linears and
+//             dgrad (with a pre-transposed weight copy).  Fused epilogues: bias, bias+GELU(erf),
+//             bias+residual+DropPath-scale (fp32 residual stream), GELU' (fc1 dgrad), region-embed
+//             row remap (+mask-token blend).
+//   gemm_nt_rows : C[N1,N2] = X[M,N1]^T * Y[M,N2]  (contraction over the ROW index of both operands)
+//             -- wgrad.  Operand fragments come out of LDS with ds_read_b64_tr_b16 (hardware transpose);
+//             split over M into fp32 slabs that reduce_slabs sums deterministically.
+//
+// Structure (v1): 128x128 output tile, BK=64, 4 waves (2x2, 64x64 per wave, 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16), operands staged global->LDS with 16-byte global_load_lds into an
+// XOR-swizzled image (conflict-free ds_read_b128 / ds_read_b64_tr_b16), two LDS buffers, one barrier per
+// K-step, XCD-aware tile order.
+#include "common.h"
+
+enum {
+    EPI_BF16 = 0,         // out0(bf16) = acc (+bias)
+    EPI_BIAS_GELU = 1,    // u = acc+bias ; out0(bf16)=u ; out1(bf16)=gelu(u)
+    EPI_BIAS_RESID = 2,   // out0(f32) = resid + rowscale[row/T] * (acc+bias)
+    EPI_DGELU = 3,        // out0(bf16) = acc * gelu'(aux)
+    EPI_EMBED = 4,        // out0(f32)[b*T+1+n] = mask ? mask_token : acc+bias
+    EPI_F32 = 5,          // out0(f32) = acc (+bias)
+};
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    int M, N, K, lda, ldb;
+    void* out0;
+    void* out1;
+    int ldo;
+    const float* bias;
+    const float* resid;
+    const float* rowscale;
+    int rows_per_sample;
+    const bf16_t* aux;
+    int ldaux;
+    const uint8_t* mask;
+    const float* mask_token;
+    int regions_per_sample;
+};
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 128)          // 128 rows x 64 bf16
+#define GEMM_LDS (4 * TILE_BYTES)       // 2 buffers x (A + B)
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
+    // v = C[m][n..n+3]
+    if (m >= p.M || n >= p.N) return;
+    if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_EMBED) {
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+    }
+    if (EPI == EPI_BF16) {
+        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
+    } else if (EPI == EPI_F32) {
+        *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (EPI == EPI_BIAS_GELU) {
+        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) =
+            pack4bf(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+    } else if (EPI == EPI_BIAS_RESID) {
+        const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + n);
+        *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) =
+            make_float4(r.x + s * v[0], r.y + s * v[1], r.z + s * v[2], r.w + s * v[3]);
+    } else if (EPI == EPI_DGELU) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
+        const float u0 = bf2f(u.x & 0xffff), u1 = bf2f(u.x >> 16), u2 = bf2f(u.y & 0xffff), u3 = bf2f(u.y >> 16);
+        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) =
+            pack4bf(v[0] * dgelu_f(u0), v[1] * dgelu_f(u1), v[2] * dgelu_f(u2), v[3] * dgelu_f(u3));
+    } else if (EPI == EPI_EMBED) {
+        const int b = m / p.regions_per_sample, r = m - b * p.regions_per_sample;
+        const size_t orow = (size_t)b * (p.regions_per_sample + 1) + 1 + r;
+        if (p.mask && p.mask[m]) {
+            const float4 t = *reinterpret_cast<const float4*>(p.mask_token + n);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+        *reinterpret_cast<float4*>((float*)p.out0 + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[N,K]^T
+// LDS image of one operand tile: [128 rows][8 chunks of 16 B], chunk index XORed with (row>>1)&7 so that
+// the 16-lane groups of ds_read_b128 (rows r..r+15 at one K-chunk) touch 16 distinct 16-B slots.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging: 16 wave-instructions (1 KiB = 8 rows) per operand tile, 4 per wave ----
+    const char* srcA[4];
+    const char* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int ra = min(m0 + row, p.M - 1);
+        const int rb = min(n0 + row, p.N - 1);
+        srcA[j] = reinterpret_cast<const char*>(p.A + (size_t)ra * p.lda) + chunk * 16;
+        srcB[j] = reinterpret_cast<const char*>(p.B + (size_t)rb * p.ldb) + chunk * 16;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* a = smem + buf * (2 * TILE_BYTES);
+        char* b = a + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(srcA[j] + (size_t)kt * (BK * 2), a + (wave * 4 + j) * 1024);
+            glds16(srcB[j] + (size_t)kt * (BK * 2), b + (wave * 4 + j) * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment offsets inside a tile (bytes): row (lane&15), K-chunk 4*ks + (lane>>4), swizzled
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 128 + (((4 * ks + (lane >> 4)) ^ fsw) << 4);
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    __syncthreads();   // (vmcnt(0) is emitted before the barrier while LDS-DMA is pending)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* a = smem + cur * (2 * TILE_BYTES) + (wr * 64) * 128;
+        const char* b = smem + cur * (2 * TILE_BYTES) + TILE_BYTES + (wc * 64) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(a + i * 16 * 128 + foff[ks]);
+                fb[i] = *reinterpret_cast<const bf16x8*>(b + i * 16 * 128 + foff[ks]);
+            }
+            // first MFMA operand = weight rows (n), second = activation rows (m):
+            // D[i][j]: i -> n = (lane>>4)*4 + reg, j -> m = lane&15  => each lane owns 4 consecutive n.
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int em = m0 + wr * 64 + (lane & 15);
+    const int en = n0 + wc * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) epilogue4<EPI>(p, em + mt * 16, en + nt * 16, acc[mt][nt]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[N1,N2] (+)= X[M,N1]^T * Y[M,N2]   (wgrad), split over M: block (tile, s) handles K-steps
+// [s*steps_per_split, ...) and writes the fp32 slab s.
+// LDS image of one operand tile: [64 rows(m)][16 chunks of 16 B] (256-B rows); chunk index XORed with
+// 2*((m&3) | ((m>>3)&1)<<2) so that the 32-lane halves of ds_read_b64_tr_b16 (8 rows x 2 chunks) are
+// conflict-free.  Rows >= M are sourced from a zero line.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const uint32_t g_zero_line[4] = {0u, 0u, 0u, 0u};
+
+struct WgradArgs {
+    const bf16_t* X;   // [M, ldx]  (dY)
+    const bf16_t* Y;   // [M, ldy]  (layer input)
+    int M, N1, N2, ldx, ldy;
+    float* slabs;      // [nsplit][N1][N2]
+    int steps_per_split;
+};
+
+__device__ __forceinline__ s16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// wgrad tile swizzle: XOR of the 16-B chunk index of row m (256-B rows)
+__device__ __forceinline__ int wg_swz(int m) { return 2 * ((m & 3) | (((m >> 3) & 1) << 2)); }
+// byte offset inside a 256-B row of element column `col` (multiple of 4) of row m
+__device__ __forceinline__ int tr_col_off(int col, int m) {
+    return (((col >> 3) ^ wg_swz(m)) << 4) | ((col & 4) << 1);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles1 = (p.N1 + 127) / 128, tiles2 = (p.N2 + 127) / 128;
+    const int ntile = tiles1 * tiles2;
+    const int split = blockIdx.x / ntile;
+    const int tile = blockIdx.x - split * ntile;
+    const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+    const int n1_0 = t1 * 128, n2_0 = t2 * 128;
+
+    const int nk_total = (p.M + BK - 1) / BK;
+    const int k_begin = split * p.steps_per_split;
+    const int k_end = min(nk_total, k_begin + p.steps_per_split);
+
+    // staging: one wave-instruction = 1 KiB = 4 rows x 256 B; 16 per operand tile, 4 per wave.
+    // lane -> row (lane>>4), physical chunk (lane&15); source chunk = phys ^ f(row).
+    int srow[4], schunk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 4 + (lane >> 4);
+        srow[j] = row;
+        schunk[j] = (lane & 15) ^ wg_swz(row);
+    }
+    // clamp columns (N1/N2 tails: extra columns are computed but never stored)
+    auto stage = [&](int buf, int kt) {
+        char* x = smem + buf * (2 * TILE_BYTES);
+        char* y = x + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = kt * BK + srow[j];
+            const int c1 = min(n1_0 + schunk[j] * 8, p.N1 - 8);
+            const int c2 = min(n2_0 + schunk[j] * 8, p.N2 - 8);
+            const void* sx = (m < p.M) ? (const void*)(p.X + (size_t)m * p.ldx + c1) : (const void*)g_zero_line;
+            const void* sy = (m < p.M) ? (const void*)(p.Y + (size_t)m * p.ldy + c2) : (const void*)g_zero_line;
+            glds16(sx, x + (wave * 4 + j) * 1024);
+            glds16(sy, y + (wave * 4 + j) * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment read: 16-lane group g = lane>>4 covers m = 8g..8g+7 (two 4-row blocks) of the
+    // 32-deep K-step; lane (4q+p) supplies &tile[m0+q][col0 + 4p].
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int toff[2][2];   // [ks][half] byte offset of this lane's address for column-chunk 0 (col0 = 0)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 8 * g + 4 * h + q;
+            toff[ks][h] = m * 256;   // chunk part added per tile below (needs XOR with f(m))
+        }
+
+    if (k_begin < k_end) {
+        stage(0, k_begin);
+        __syncthreads();
+        for (int kt = k_begin; kt < k_end; ++kt) {
+            const int cur = (kt - k_begin) & 1;
+            if (kt + 1 < k_end) stage(cur ^ 1, kt + 1);
+            const char* x = smem + cur * (2 * TILE_BYTES);
+            const char* y = x + TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fx[4], fy[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // X columns (n1): wr*64 + i*16 ; Y columns (n2): wc*64 + i*16
+                    const int m_lo = ks * 32 + 8 * g + q, m_hi = m_lo + 4;
+                    const int colx = wr * 64 + i * 16 + 4 * pp;   // element column inside the X tile
+                    const int coly = wc * 64 + i * 16 + 4 * pp;
+                    fx[i] = join_tr(lds_tr16(x + toff[ks][0] + tr_col_off(colx, m_lo)),
+                                    lds_tr16(x + toff[ks][1] + tr_col_off(colx, m_hi)));
+                    fy[i] = join_tr(lds_tr16(y + toff[ks][0] + tr_col_off(coly, m_lo)),
+                                    lds_tr16(y + toff[ks][1] + tr_col_off(coly, m_hi)));
+                }
+                // first operand = Y fragment (i -> n2), second = X fragment (j -> n1):
+                // D[i][j] = sum_m Y[m][i] X[m][j]; lane owns n1 = lane&15, n2 = (lane>>4)*4 + reg.
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[b], fx[a], acc[a][b], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    float* out = p.slabs + (size_t)split * p.N1 * p.N2;
+    const int e1 = n1_0 + wr * 64 + (lane & 15);
+    const int e2 = n2_0 + wc * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = e1 + a * 16, c = e2 + b * 16;
+            if (r < p.N1 && c < p.N2)
+                *reinterpret_cast<float4*>(out + (size_t)r * p.N2 + c) =
+                    make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]        (n % 4 == 0)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n,
+                                    int nsplit, int accumulate) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)k * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers (internal C++ API used by capi.hip)
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_set = true;
+    }
+    const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS, st, a);
+    GETMI_CHECK_LAUNCH("gemm_tn");
+    return GETMI_OK;
+}
+
+int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
+    GETMI_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    GETMI_CHECK_ARG(a.K % BK == 0, "gemm_tn: K=%d must be a multiple of %d (pad the operands)", a.K, BK);
+    GETMI_CHECK_ARG(a.N % 4 == 0 && a.ldo % 4 == 0, "gemm_tn: N=%d and ldo=%d must be multiples of 4", a.N, a.ldo);
+    GETMI_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0, "gemm_tn: lda/ldb must be multiples of 8 (16-byte rows)");
+    GETMI_CHECK_ARG(a.lda >= a.K && a.ldb >= a.K && a.ldo >= a.N, "gemm_tn: leading dimension too small");
+    GETMI_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.out0 % 16 == 0),
+                    "gemm_tn: pointers must be 16-byte aligned");
+    switch (epi) {
+        case EPI_BF16: return launch_gemm_tn<EPI_BF16>(a, st);
+        case EPI_BIAS_GELU:
+            GETMI_CHECK_ARG(a.out1 && a.bias, "gemm_tn: bias_gelu needs out1 and bias");
+            return launch_gemm_tn<EPI_BIAS_GELU>(a, st);
+        case EPI_BIAS_RESID:
+            GETMI_CHECK_ARG(a.resid && (!a.rowscale || a.rows_per_sample > 0), "gemm_tn: bias_resid needs resid");
+            return launch_gemm_tn<EPI_BIAS_RESID>(a, st);
+        case EPI_DGELU:
+            GETMI_CHECK_ARG(a.aux && a.ldaux % 4 == 0, "gemm_tn: dgelu needs aux");
+            return launch_gemm_tn<EPI_DGELU>(a, st);
+        case EPI_EMBED:
+            GETMI_CHECK_ARG(a.regions_per_sample > 0 && a.M % a.regions_per_sample == 0,
+                            "gemm_tn: embed needs regions_per_sample dividing M");
+            GETMI_CHECK_ARG(!a.mask || a.mask_token, "gemm_tn: embed mask needs mask_token");
+            return launch_gemm_tn<EPI_EMBED>(a, st);
+        case EPI_F32: return launch_gemm_tn<EPI_F32>(a, st);
+    }
+    getmi_set_error("gemm_tn: unknown epilogue %d", epi);
+    return GETMI_ERR_ARG;
+}
+
+// choose the number of M-splits so that tiles*splits fills the chip (~2 blocks per CU on 256 CUs)
+int getmi_wgrad_nsplit(int M, int N1, int N2) {
+    const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    const int nk = (M + BK - 1) / BK;
+    int want = (512 + ntile - 1) / ntile;
+    if (want < 1) want = 1;
+    if (want > nk) want = nk;
+    if (want > 64) want = 64;
+    const int steps = (nk + want - 1) / want;
+    return (nk + steps - 1) / steps;
+}
+
+int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N2, int ldx, int ldy, float* out,
+                          int accumulate, float* slabs, size_t slab_bytes, hipStream_t st) {
+    GETMI_CHECK_ARG(M > 0 && N1 >= 8 && N2 >= 8, "gemm_wgrad: bad shape M=%d N1=%d N2=%d", M, N1, N2);
+    GETMI_CHECK_ARG(N1 % 8 == 0 && N2 % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0,
+                    "gemm_wgrad: N1, N2, ldx, ldy must be multiples of 8");
+    GETMI_CHECK_ARG(((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                        ((uintptr_t)slabs % 16 == 0),
+                    "gemm_wgrad: pointers must be 16-byte aligned");
+    const int nsplit = getmi_wgrad_nsplit(M, N1, N2);
+    GETMI_CHECK_ARG(slab_bytes >= (size_t)nsplit * N1 * N2 * sizeof(float),
+                    "gemm_wgrad: workspace too small (%zu < %zu)", slab_bytes, (size_t)nsplit * N1 * N2 * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        attr_set = true;
+    }
+    WgradArgs a;
+    a.X = X; a.Y = Y; a.M = M; a.N1 = N1; a.N2 = N2; a.ldx = ldx; a.ldy = ldy; a.slabs = slabs;
+    const int nk = (M + BK - 1) / BK;
+    a.steps_per_split = (nk + nsplit - 1) / nsplit;
+    const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(ntile * nsplit), dim3(256), GEMM_LDS, st, a);
+    GETMI_CHECK_LAUNCH("gemm_wgrad");
+    const size_t n = (size_t)N1 * N2;
+    int rgrid = (int)((n / 4 + 255) / 256);
+    if (rgrid > 2048) rgrid = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rgrid), dim3(256), 0, st, slabs, out, n, nsplit, accumulate);
+    GETMI_CHECK_LAUNCH("reduce_slabs");
+    return GETMI_OK;
+}

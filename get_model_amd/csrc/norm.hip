@@ -1,0 +1,198 @@
+// LayerNorm forward / backward for the fp32 residual stream (HBM-bound; one wave per token row).
+//
+// Replaces norm1 / norm2 / encoder.norm (model/transformer.py:198,221,344; eps 1e-6 from :315) and, in the
+// backward, also folds in the residual-gradient add, the per-sample DropPath scale of the *previous*
+// branch and the bf16 cast that the preceding GEMMs' dgrad/wgrad consume, plus the column sums that are
+// the previous Linear's bias gradient:
+//     dx  = dres + LN'(dy)                       (fp32, the gradient of the residual stream)
+//     dz  = bf16(rowscale[row/T] * dx)           (gradient w.r.t. the previous branch's Linear output)
+//     partial[blk] = column sums over the block's rows of {dy*xhat, dy, dz}
+// Algorithmic bytes per row (D=768): fwd 4*D read + 2*D write; bwd (2+4+4)*D read + (4+2)*D write.
+#include "common.h"
+
+template <int NV>  // D = NV * 256
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                     float eps) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NV], bt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        g[v] = *reinterpret_cast<const float4*>(gamma + (v * 64 + lane) * 4);
+        bt[v] = *reinterpret_cast<const float4*>(beta + (v * 64 + lane) * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * D;
+        float4 a[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            a[v] = *reinterpret_cast<const float4*>(xr + (v * 64 + lane) * 4);
+            s += a[v].x + a[v].y + a[v].z + a[v].w;
+        }
+        const float mu = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            a[v].x -= mu; a[v].y -= mu; a[v].z -= mu; a[v].w -= mu;
+            q += a[v].x * a[v].x + a[v].y * a[v].y + a[v].z * a[v].z + a[v].w * a[v].w;
+        }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+        bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            *reinterpret_cast<uint2*>(yr + (v * 64 + lane) * 4) =
+                pack4bf(a[v].x * rs * g[v].x + bt[v].x, a[v].y * rs * g[v].y + bt[v].y,
+                        a[v].z * rs * g[v].z + bt[v].z, a[v].w * rs * g[v].w + bt[v].w);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     const float* __restrict__ rowscale, int rows_per_sample,
+                                                     float* __restrict__ dx, bf16_t* __restrict__ dz,
+                                                     float* __restrict__ partial, int M) {
+    constexpr int D = NV * 256;
+    __shared__ __attribute__((aligned(16))) float red[3][4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NV], ag[NV], ab[NV], az[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        g[v] = *reinterpret_cast<const float4*>(gamma + (v * 64 + lane) * 4);
+        ag[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[v] = ag[v];
+        az[v] = ag[v];
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float sc = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+        float4 xh[NV], d[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * D + (v * 64 + lane) * 4);
+            const uint2 dv = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + (v * 64 + lane) * 4);
+            xh[v] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            d[v] = make_float4(bf2f(dv.x & 0xffff), bf2f(dv.x >> 16), bf2f(dv.y & 0xffff), bf2f(dv.y >> 16));
+            ag[v].x += d[v].x * xh[v].x; ag[v].y += d[v].y * xh[v].y;
+            ag[v].z += d[v].z * xh[v].z; ag[v].w += d[v].w * xh[v].w;
+            ab[v].x += d[v].x; ab[v].y += d[v].y; ab[v].z += d[v].z; ab[v].w += d[v].w;
+            d[v].x *= g[v].x; d[v].y *= g[v].y; d[v].z *= g[v].z; d[v].w *= g[v].w;
+            c1 += d[v].x + d[v].y + d[v].z + d[v].w;
+            c2 += d[v].x * xh[v].x + d[v].y * xh[v].y + d[v].z * xh[v].z + d[v].w * xh[v].w;
+        }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 o = make_float4(rs * (d[v].x - c1 - xh[v].x * c2), rs * (d[v].y - c1 - xh[v].y * c2),
+                                   rs * (d[v].z - c1 - xh[v].z * c2), rs * (d[v].w - c1 - xh[v].w * c2));
+            if (dres) {
+                const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * D + (v * 64 + lane) * 4);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(dx + (size_t)row * D + (v * 64 + lane) * 4) = o;
+            if (dz) {
+                const float4 z = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
+                *reinterpret_cast<uint2*>(dz + (size_t)row * D + (v * 64 + lane) * 4) = pack4bf(z.x, z.y, z.z, z.w);
+                az[v].x += z.x; az[v].y += z.y; az[v].z += z.z; az[v].w += z.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        *reinterpret_cast<float4*>(&red[0][wave][(v * 64 + lane) * 4]) = ag[v];
+        *reinterpret_cast<float4*>(&red[1][wave][(v * 64 + lane) * 4]) = ab[v];
+        *reinterpret_cast<float4*>(&red[2][wave][(v * 64 + lane) * 4]) = az[v];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
+        const int k = i / D, c = i - k * D;
+        partial[((size_t)k * gridDim.x + blockIdx.x) * D + c] = red[k][0][c] + red[k][1][c] + red[k][2][c] + red[k][3][c];
+    }
+}
+
+// out_k[c] (+)= sum_r partial[k][r][c]   for k = blockIdx.y; 64 columns x 16 row groups per block
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ partial, float* out0, float* out1,
+                                                         float* out2, int R, int C, int accumulate) {
+    __shared__ float red[16][64];
+    const int k = blockIdx.y;
+    float* out = k == 0 ? out0 : (k == 1 ? out1 : out2);
+    if (out == nullptr) return;   // block-uniform
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < C)
+        for (int r = ty; r < R; r += 16) s += partial[((size_t)k * R + r) * C + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, 3), dim3(1024), 0, st, partial, out0, out1, out2, R, C,
+                       accumulate);
+    GETMI_CHECK_LAUNCH("colreduce");
+    return GETMI_OK;
+}
+
+static int ln_grid(int M) {
+    int g = (M + 3) / 4;
+    if (g > 1024) g = 1024;
+    return g < 1 ? 1 : g;
+}
+
+int getmi_ln_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                      int M, int D, float eps, hipStream_t st) {
+    GETMI_CHECK_ARG(M > 0, "ln_fwd: M=%d", M);
+    GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "ln_fwd: D=%d unsupported (256,512,768,1024)", D);
+    const int g = ln_grid(M);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(g), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(g), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, dim3(g), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3(g), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, M, eps); break;
+    }
+    GETMI_CHECK_LAUNCH("ln_fwd");
+    return GETMI_OK;
+}
+
+size_t getmi_ln_bwd_workspace_bytes(int M, int D) { return (size_t)3 * ln_grid(M) * D * sizeof(float); }
+
+// dgamma/dbeta/dbias_prev: [D] each (dbias_prev may be null); accumulate: add into existing values
+int getmi_ln_bwd_impl(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dres, const float* rowscale, int rows_per_sample, float* dx, bf16_t* dz,
+                      float* dgamma, float* dbeta, float* dbias_prev, int accumulate, int M, int D, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+    GETMI_CHECK_ARG(M > 0, "ln_bwd: M=%d", M);
+    GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "ln_bwd: D=%d unsupported", D);
+    GETMI_CHECK_ARG(workspace_bytes >= getmi_ln_bwd_workspace_bytes(M, D), "ln_bwd: workspace too small");
+    GETMI_CHECK_ARG(!rowscale || rows_per_sample > 0, "ln_bwd: rows_per_sample");
+    GETMI_CHECK_ARG(!dbias_prev || dz, "ln_bwd: dbias_prev needs dz");
+    const int g = ln_grid(M);
+    float* partial = reinterpret_cast<float*>(workspace);
+#define LN_BWD_LAUNCH(NV)                                                                                         \
+    hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(g), dim3(256), 0, st, dy, x, mean, rstd, gamma, dres, rowscale,   \
+                       rows_per_sample, dx, dz, partial, M)
+    switch (D / 256) {
+        case 1: LN_BWD_LAUNCH(1); break;
+        case 2: LN_BWD_LAUNCH(2); break;
+        case 3: LN_BWD_LAUNCH(3); break;
+        case 4: LN_BWD_LAUNCH(4); break;
+    }
+#undef LN_BWD_LAUNCH
+    GETMI_CHECK_LAUNCH("ln_bwd");
+    if (int rc = getmi_colreduce_impl(partial, dgamma, dbeta, dbias_prev, g, D, accumulate, st)) return rc;
+    return GETMI_OK;
+}

@@ -1,0 +1,218 @@
+"""Tensor-level wrappers of the C-ABI kernels (one Python function per entry point of include/getmi355.h).
+
+torch is used only to allocate device buffers and to provide the stream; all arithmetic happens in
+libgetmi355.so.  Every function requires CUDA(HIP) tensors and raises RuntimeError otherwise.
+"""
+import torch
+
+from . import lib
+
+EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_EMBED, EPI_F32 = range(6)
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous()):
+            raise RuntimeError("getmi355 kernels need contiguous tensors on the GPU (no CPU fallback exists)")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def cast_pad(src, cp=None):
+    """fp32 [R,C] -> bf16 [R,Cp] (zero padded)."""
+    _chk(src)
+    R, C = src.shape
+    cp = C if cp is None else cp
+    dst = torch.empty(R, cp, dtype=BF16, device=src.device)
+    lib.call("getmi_cast_pad_f32_bf16", src, dst, R, C, cp)
+    return dst
+
+
+def cast_bf16(src):
+    """fp32 tensor -> bf16 tensor of the same shape (numel % 4 == 0)."""
+    _chk(src)
+    n = src.numel()
+    dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    lib.call("getmi_cast_pad_f32_bf16", src, dst, 1, n, n)
+    return dst
+
+
+def cast_transpose(src):
+    """fp32 [R,C] -> bf16 [C,R]."""
+    _chk(src)
+    R, C = src.shape
+    dst = torch.empty(C, R, dtype=BF16, device=src.device)
+    lib.call("getmi_cast_transpose_f32_bf16", src, dst, R, C)
+    return dst
+
+
+def qkv_bias(q_bias, v_bias):
+    _chk(q_bias, v_bias)
+    D = q_bias.numel()
+    out = torch.empty(3 * D, dtype=F32, device=q_bias.device)
+    lib.call("getmi_qkv_bias", q_bias, v_bias, out, D)
+    return out
+
+
+def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, rows_per_sample=0, aux=None,
+            mask=None, mask_token=None, regions_per_sample=0, M=None):
+    """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated."""
+    _chk(A, B, out0, out1, bias, resid, rowscale, aux, mask, mask_token)
+    M = A.shape[0] if M is None else M
+    K = A.shape[1]
+    N = B.shape[0]
+    assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
+    lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, out0.shape[-1], bias,
+             resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
+             regions_per_sample)
+    return out0
+
+
+def gemm_wgrad(X, Y, out=None, accumulate=False):
+    """out[N1,N2] (+)= X[M,N1]^T @ Y[M,N2]  (fp32)."""
+    _chk(X, Y, out)
+    M, N1 = X.shape
+    N2 = Y.shape[1]
+    assert Y.shape[0] == M and X.dtype == BF16 and Y.dtype == BF16
+    if out is None:
+        out = torch.empty(N1, N2, dtype=F32, device=X.device)
+        accumulate = False
+    nbytes = lib.query("getmi_gemm_wgrad_workspace_bytes", M, N1, N2)
+    ws = _ws(nbytes, X.device)
+    lib.call("getmi_gemm_wgrad", X, Y, M, N1, N2, X.stride(0), Y.stride(0), out, int(accumulate), ws, ws.numel())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6):
+    """x fp32 [M,D] -> (y bf16 [M,D], mean [M], rstd [M])."""
+    _chk(x, gamma, beta)
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=BF16, device=x.device)
+    mean = torch.empty(M, dtype=F32, device=x.device)
+    rstd = torch.empty(M, dtype=F32, device=x.device)
+    lib.call("getmi_layernorm_fwd", x, gamma, beta, y, mean, rstd, M, D, float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, rowscale=None, rows_per_sample=0, want_dz=False,
+                  want_dbias=False):
+    """Returns (dx fp32, dz bf16|None, dgamma, dbeta, dbias_prev|None)."""
+    _chk(dy, x, mean, rstd, gamma, dres, rowscale)
+    M, D = x.shape
+    dev = x.device
+    dx = torch.empty(M, D, dtype=F32, device=dev)
+    dz = torch.empty(M, D, dtype=BF16, device=dev) if want_dz else None
+    dgamma = torch.empty(D, dtype=F32, device=dev)
+    dbeta = torch.empty(D, dtype=F32, device=dev)
+    dbias = torch.empty(D, dtype=F32, device=dev) if want_dbias else None
+    ws = _ws(lib.query("getmi_layernorm_bwd_workspace_bytes", M, D), dev)
+    lib.call("getmi_layernorm_bwd", dy, x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, dz, dgamma, dbeta,
+             dbias, 0, M, D, ws, ws.numel())
+    return dx, dz, dgamma, dbeta, dbias
+
+
+def attention_fwd(qkv, B, T, H, scale):
+    """qkv bf16 [B*T, 3*H*64] (packed [B,T,3,H,64]) -> (out bf16 [B*T, H*64], lse fp32 [B,H,T])."""
+    _chk(qkv)
+    out = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=F32, device=qkv.device)
+    lib.call("getmi_attention_fwd", qkv, out, lse, B, T, H, float(scale))
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, T, H, scale):
+    _chk(qkv, out, dout, lse)
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
+    lib.call("getmi_attention_bwd", qkv, out, dout, lse, dqkv, B, T, H, float(scale), ws, ws.numel())
+    return dqkv
+
+
+def fill_cls(x0, cls_token, B, T, D):
+    _chk(x0, cls_token)
+    lib.call("getmi_fill_cls", x0, cls_token, B, T, D)
+
+
+def embed_bwd_prep(dx0, mask_u8, B, N, D):
+    """-> (dz bf16 [B*N,D], dcls [D], dmask_token [D], dbias [D])."""
+    _chk(dx0, mask_u8)
+    dev = dx0.device
+    dz = torch.empty(B * N, D, dtype=BF16, device=dev)
+    dcls = torch.empty(D, dtype=F32, device=dev)
+    dmt = torch.empty(D, dtype=F32, device=dev)
+    dbias = torch.empty(D, dtype=F32, device=dev)
+    ws = _ws(lib.query("getmi_embed_bwd_workspace_bytes", B, N, D), dev)
+    lib.call("getmi_embed_bwd_prep", dx0, mask_u8, dz, dcls, dmt, dbias, 0, B, N, D, ws, ws.numel())
+    return dz, dcls, dmt, dbias
+
+
+def head_fwd(hf, W, bias, B, N):
+    _chk(hf, W, bias)
+    out_dim, D = W.shape
+    logits = torch.empty(B, N, out_dim, dtype=F32, device=hf.device)
+    pred = torch.empty(B, N, out_dim, dtype=F32, device=hf.device)
+    lib.call("getmi_head_fwd", hf, W, bias, logits, pred, B, N, D, out_dim)
+    return logits, pred
+
+
+def head_bwd(dpred, logits, hf, W, B, N):
+    """-> (dh bf16 [B*(N+1), D], dW [out,D], db [out])."""
+    _chk(dpred, logits, hf, W)
+    out_dim, D = W.shape
+    dev = hf.device
+    dh = torch.empty(B * (N + 1), D, dtype=BF16, device=dev)
+    dwb = torch.empty(out_dim * D + out_dim, dtype=F32, device=dev)
+    ws = _ws(lib.query("getmi_head_bwd_workspace_bytes", B, N, D, out_dim), dev)
+    lib.call("getmi_head_bwd", dpred, logits, hf, W, dh, dwb, 0, B, N, D, out_dim, ws, ws.numel())
+    return dh, dwb[: out_dim * D].view(out_dim, D), dwb[out_dim * D:]
+
+
+LOSS_POISSON, LOSS_MSE = 0, 1
+
+
+def loss_fwd(kind, pred, obs, weight=1.0, eps=1e-8):
+    """pred/obs: 2-D views [R, C] with unit column stride -> (loss scalar tensor, grad_unit like pred)."""
+    assert pred.dim() == 2 and obs.dim() == 2 and pred.stride(1) == 1 and obs.stride(1) == 1
+    if not (pred.is_cuda and obs.is_cuda):
+        raise RuntimeError("getmi355 kernels need GPU tensors")
+    R, C = pred.shape
+    loss = torch.empty((), dtype=F32, device=pred.device)
+    grad = torch.empty(R, C, dtype=F32, device=pred.device)
+    ws = _ws(lib.query("getmi_loss_workspace_bytes"), pred.device)
+    lib.call("getmi_loss_fwd", kind, pred, obs, loss, grad, R, C, pred.stride(0), obs.stride(0), C, float(weight),
+             float(eps), ws, ws.numel())
+    return loss, grad
+
+
+def scale_by_scalar(x, scalar, weight=1.0):
+    _chk(x, scalar)
+    out = torch.empty_like(x)
+    lib.call("getmi_scale_by_scalar", x, scalar, float(weight), out, x.numel())
+    return out
+
+
+def gather_rows(src, idx, n_out=None, scatter=False):
+    """gather: dst[i] = src[idx[i]]; scatter: dst[idx[i]] = src[i] (dst zero-initialised, n_out rows)."""
+    _chk(src, idx)
+    D = src.shape[1]
+    n = idx.numel()
+    if scatter:
+        dst = torch.zeros(n_out, D, dtype=BF16, device=src.device)
+    else:
+        dst = torch.empty(n, D, dtype=BF16, device=src.device)
+    lib.call("getmi_gather_rows_bf16", src, idx, dst, n, D, int(scatter))
+    return dst
+
+
+def colsum_bf16(X, M=None):
+    _chk(X)
+    M = X.shape[0] if M is None else M
+    N = X.shape[1]
+    out = torch.empty(N, dtype=F32, device=X.device)
+    ws = _ws(lib.query("getmi_colsum_workspace_bytes", N), X.device)
+    lib.call("getmi_colsum_bf16", X, out, 0, M, N, X.stride(0), ws, ws.numel())
+    return out

@@ -1,0 +1,111 @@
+/* getmi355 -- C ABI of the MI355X (gfx950) kernels behind the GET region-transformer hot path.
+ *
+ * The reference (GET-Foundation/get_model) has no native code and therefore no FFI for this path: the
+ * "interface each entry point replaces" is the eager PyTorch call site in the reference's Python, cited
+ * per function below (paths relative to the reference's get_model/).  Host code (get_model_amd/, Python)
+ * binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (torch tensors' data_ptr()).
+ *  - bf16 buffers are passed as void* (raw 16-bit words); fp32 as float*.
+ *  - stream is a hipStream_t passed as void* (0 = default stream).  Calls only ENQUEUE work and return.
+ *  - return 0 on success; non-zero on error (1 = bad argument, 2 = launch failure); message via
+ *    getmi_last_error() (thread-local).  No exceptions, no exit().
+ *  - the library never allocates device memory: scratch comes in through (workspace, workspace_bytes),
+ *    sized by the matching *_workspace_bytes() query.  Workspaces must be 256-byte aligned.
+ *  - re-entrant; no mutable global state besides one-time kernel attribute set-up.
+ */
+#ifndef GETMI355_H
+#define GETMI355_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* getmi_last_error(void);
+int getmi_version(void);          /* 100 = 1.0.0 */
+const char* getmi_arch(void);     /* "gfx950" */
+
+/* ---- packing -------------------------------------------------------------------------------- */
+/* fp32 [R,C] -> bf16 [R,Cp], zero-padding columns C..Cp-1 (Cp % 4 == 0).  Replaces the implicit fp32
+ * operand use of nn.Linear (model/modules.py:101-103, model/transformer.py:57,97,172,175). */
+int getmi_cast_pad_f32_bf16(const float* src, void* dst, int64_t R, int C, int Cp, void* stream);
+/* fp32 [R,C] -> bf16 [C,R]: transposed weight copy consumed by the dgrad GEMMs (autograd of F.linear). */
+int getmi_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, void* stream);
+/* out[3D] = [q_bias, 0, v_bias]   (model/transformer.py:50-56 torch.cat) */
+int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, void* stream);
+
+/* ---- GEMM ----------------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] * B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue `epi`:
+ *   0 BF16        out0(bf16)[M,ldo] = acc (+bias)                       qkv: transformer.py:57
+ *   1 BIAS_GELU   out0(bf16)=u=acc+bias ; out1(bf16)=gelu_erf(u)        fc1+act: transformer.py:172-173
+ *   2 BIAS_RESID  out0(f32) = resid + rowscale[row/rows_per_sample]*(acc+bias)
+ *                                                                       proj/fc2 + DropPath + residual:
+ *                                                                       transformer.py:97,175,247-248
+ *   3 DGELU       out0(bf16) = acc * gelu'(aux)                         autograd of :173
+ *   4 EMBED       out0(f32)[b*(R+1)+1+r] = mask[m] ? mask_token : acc+bias  (R = regions_per_sample)
+ *                                                                       modules.py:101-103, model.py:520-525
+ *   5 F32         out0(f32) = acc (+bias)                               head_mask: model.py:528
+ * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned pointers.  Unused pointers may be NULL. */
+int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0,
+                  void* out1, int ldo, const float* bias, const float* resid, const float* rowscale,
+                  int rows_per_sample, const void* aux, int ldaux, const uint8_t* mask, const float* mask_token,
+                  int regions_per_sample, void* stream);
+/* out[N1,N2] (+)= X[M,N1]^T * Y[M,N2]  (weight gradient; autograd of F.linear).  bf16 operands, fp32 out. */
+size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2);
+int getmi_gemm_wgrad(const void* X, const void* Y, int M, int N1, int N2, int ldx, int ldy, float* out,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm (model/transformer.py:198,221,243,248,344,364; eps from :315) ------------------ */
+int getmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean,
+                        float* rstd, int M, int D, float eps, void* stream);
+size_t getmi_layernorm_bwd_workspace_bytes(int M, int D);
+/* dx = dres + LN'(dy); dz = bf16(rowscale*dx) (optional); dgamma, dbeta, dbias_prev = column sums. */
+int getmi_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                        const float* gamma, const float* dres, const float* rowscale, int rows_per_sample,
+                        float* dx, void* dz_bf16, float* dgamma, float* dbeta, float* dbias_prev, int accumulate,
+                        int M, int D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- attention (model/transformer.py:58-96), packed qkv[B,T,3,H,64] bf16, head_dim 64 ---------- */
+int getmi_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale, void* stream);
+size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H);
+int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                        int T, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- region embed glue (model/model.py:520-525,571-573) ---------------------------------------- */
+int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream);
+size_t getmi_embed_bwd_workspace_bytes(int B, int N, int D);
+int getmi_embed_bwd_prep(const float* dx0, const uint8_t* mask, void* dz_bf16, float* dcls, float* dmask_token,
+                         float* dbias, int accumulate, int B, int N, int D, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ---- expression head + softplus (model/model.py:575-576, model/modules.py:255-258) -------------- */
+int getmi_head_fwd(const void* hf_bf16, const float* W, const float* bias, float* logits, float* pred, int B,
+                   int N, int D, int out_dim, void* stream);
+size_t getmi_head_bwd_workspace_bytes(int B, int N, int D, int out_dim);
+int getmi_head_bwd(const float* dpred, const float* logits, const void* hf_bf16, const float* W, void* dh_bf16,
+                   float* dwb, int accumulate, int B, int N, int D, int out_dim, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- losses (model/model.py:144-149 with torch.nn.PoissonNLLLoss / torch.nn.MSELoss, mean) ------ */
+size_t getmi_loss_workspace_bytes(void);
+/* kind 0 = Poisson NLL (log_input=False, full=False), 1 = MSE.  loss[0] = weight*mean(...);
+ * grad_unit = d(mean loss)/d(pred) (unweighted). */
+int getmi_loss_fwd(int kind, const float* pred, const float* obs, float* loss, float* grad_unit, int64_t R,
+                   int C, int ldp, int ldo, int ldg, float weight, float eps, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int getmi_scale_by_scalar(const float* in, const float* scalar_dev, float weight, float* out, int64_t n,
+                          void* stream);
+
+/* ---- masked-row gather/scatter (model/model.py:527,535), column sums (bias gradients) ----------- */
+int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int D, int scatter,
+                           void* stream);
+size_t getmi_colsum_workspace_bytes(int N);
+int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

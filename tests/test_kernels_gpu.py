@@ -1,0 +1,276 @@
+"""GPU: every C-ABI kernel against a plain torch fp32 restatement of the same op on the same (bf16-rounded)
+inputs.  Tolerances are stated per test: bf16 outputs carry one rounding (rel 2^-8 = 3.9e-3)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd import kernels
+    return kernels
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.float()
+    b = b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} mismatches, max err {err.max().item():.4e}, ref max {b.abs().max().item():.3e}"
+
+
+def test_cast_and_transpose(K):
+    x = rnd(37, 283, seed=1)
+    y = K.cast_pad(x, 320)
+    assert y.shape == (37, 320)
+    assert torch.equal(y[:, :283], bf(x)) and (y[:, 283:] == 0).all()
+    w = rnd(96, 200, seed=2)
+    assert torch.equal(K.cast_transpose(w), bf(w).t().contiguous())
+    v = rnd(3 * 768, seed=3)
+    assert torch.equal(K.cast_bf16(v), bf(v))
+    qb = K.qkv_bias(v[:768].contiguous(), v[768:1536].contiguous())
+    assert torch.equal(qb[:768], v[:768]) and (qb[768:1536] == 0).all() and torch.equal(qb[1536:], v[768:1536])
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (201, 768, 768), (804, 2304, 768), (333, 3072, 768),
+                                    (402, 768, 3072), (1000, 768, 320)])
+def test_gemm_tn_plain_asymmetric(K, M, N, K_):
+    # asymmetric integer-valued operands: exact in bf16/fp32, catches any row/col or k-order mix-up
+    A = ((torch.arange(M * K_).reshape(M, K_) * 7 + 3) % 13 - 6).float().cuda()
+    B = ((torch.arange(N * K_).reshape(N, K_) * 5 + 1) % 11 - 5).float().cuda()
+    ref = A @ B.t()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    K.gemm_tn(K.EPI_F32, bf(A), bf(B), out)
+    assert torch.equal(out, ref)
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    K.gemm_tn(K.EPI_BF16, bf(A), bf(B), outb)
+    assert torch.equal(outb, bf(ref))
+
+
+def test_gemm_tn_epilogues(K):
+    M, N, K_, T = 402, 768, 768, 201
+    A, W = bf(rnd(M, K_, seed=4)), bf(rnd(N, K_, scale=0.05, seed=5))
+    bias = rnd(N, scale=0.1, seed=6)
+    ref = A.float() @ W.float().t() + bias
+    # bias -> bf16
+    o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    K.gemm_tn(K.EPI_BF16, A, W, o, bias=bias)
+    close(o, ref, 4e-3, 1e-3, "bias")
+    # bias + gelu
+    u = torch.empty_like(o)
+    g = torch.empty_like(o)
+    K.gemm_tn(K.EPI_BIAS_GELU, A, W, u, out1=g, bias=bias)
+    close(u, ref, 4e-3, 1e-3, "gelu.u")
+    close(g, F.gelu(ref), 4e-3, 1e-3, "gelu.g")
+    # bias + residual + per-sample scale (fp32 out)
+    resid = rnd(M, N, seed=7)
+    rs = torch.tensor([0.0, 1.0 / 0.9], device="cuda")
+    x = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    K.gemm_tn(K.EPI_BIAS_RESID, A, W, x, bias=bias, resid=resid, rowscale=rs, rows_per_sample=T)
+    refx = resid + ref * rs.repeat_interleave(T)[:, None]
+    close(x, refx, 1e-5, 1e-4, "resid")
+    K.gemm_tn(K.EPI_BIAS_RESID, A, W, x, bias=bias, resid=resid)
+    close(x, resid + ref, 1e-5, 1e-4, "resid-noscale")
+    # dgelu
+    pre = bf(rnd(M, N, seed=8))
+    d = torch.empty_like(o)
+    K.gemm_tn(K.EPI_DGELU, A, W, d, aux=pre)
+    xp = pre.float().requires_grad_(True)
+    F.gelu(xp).sum().backward()
+    close(d, (A.float() @ W.float().t()) * xp.grad, 4e-3, 2e-3, "dgelu")
+
+
+def test_gemm_tn_embed(K):
+    B_, Nr, D, Kp = 3, 50, 768, 320
+    A = bf(rnd(B_ * Nr, Kp, seed=9))
+    W = bf(rnd(D, Kp, scale=0.05, seed=10))
+    bias = rnd(D, scale=0.1, seed=11)
+    mt = rnd(D, seed=12)
+    mask = (torch.rand(B_ * Nr, generator=torch.Generator().manual_seed(1)) < 0.5).to(torch.uint8).cuda()
+    x0 = torch.full((B_ * (Nr + 1), D), 777.0, device="cuda")
+    K.gemm_tn(K.EPI_EMBED, A, W, x0, bias=bias, mask=mask, mask_token=mt, regions_per_sample=Nr)
+    ref = A.float() @ W.float().t() + bias
+    ref = torch.where(mask.bool()[:, None], mt[None, :], ref)
+    x0 = x0.view(B_, Nr + 1, D)
+    assert (x0[:, 0] == 777.0).all()
+    close(x0[:, 1:].reshape(-1, D), ref, 1e-5, 1e-4, "embed")
+    cls = rnd(D, seed=13)
+    K.fill_cls(x0, cls, B_, Nr + 1, D)
+    assert torch.equal(x0[:, 0], cls.expand(B_, D))
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (201, 768, 768), (1005, 768, 2304), (804, 3072, 768),
+                                     (130, 768, 320), (4000, 288, 768)])
+def test_gemm_wgrad_asymmetric(K, M, N1, N2):
+    X = ((torch.arange(M * N1).reshape(M, N1) * 7 + 3) % 5 - 2).float().cuda()
+    Y = ((torch.arange(M * N2).reshape(M, N2) * 3 + 1) % 7 - 3).float().cuda()
+    ref = X.t() @ Y
+    out = K.gemm_wgrad(bf(X), bf(Y))
+    assert torch.equal(out, ref), f"max err {(out - ref).abs().max().item()}"
+    out2 = K.gemm_wgrad(bf(X), bf(Y), out=out.clone(), accumulate=True)
+    assert torch.equal(out2, 2 * ref)
+
+
+@pytest.mark.parametrize("M", [1, 7, 804, 5000])
+def test_layernorm_fwd_bwd(K, M):
+    D, T = 768, 201
+    x = rnd(M, D, scale=2.0, seed=14) + 0.3
+    gamma = 1 + rnd(D, scale=0.1, seed=15)
+    beta = rnd(D, scale=0.1, seed=16)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    close(y, ref, 4e-3, 1e-3, "ln.y")
+    close(mean, x.mean(1), 1e-5, 1e-5, "ln.mean")
+    dy = bf(rnd(M, D, seed=17))
+    dres = rnd(M, D, seed=18)
+    nb = (M + T - 1) // T
+    rs = (torch.arange(nb, device="cuda") % 3).float() / 0.9
+    ref.backward(dy.float())
+    dx, dz, dg, db, dbias = K.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, rowscale=rs, rows_per_sample=T,
+                                            want_dz=True, want_dbias=True)
+    refdx = xr.grad + dres
+    close(dx, refdx, 1e-4, 1e-4, "ln.dx")
+    refdz = refdx * rs.repeat_interleave(T)[:M, None]
+    close(dz, refdz, 4e-3, 1e-3, "ln.dz")
+    close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(M), "ln.dgamma")
+    close(db, br.grad, 1e-3, 1e-3 * math.sqrt(M), "ln.dbeta")
+    close(dbias, refdz.sum(0), 1e-3, 1e-3 * math.sqrt(M), "ln.dbias_prev")
+    dx2, dz2, _, _, _ = K.layernorm_bwd(dy, x, mean, rstd, gamma)
+    close(dx2, xr.grad, 1e-4, 1e-4, "ln.dx-nores")
+    assert dz2 is None
+
+
+def attn_ref(qkv, B, T, H, scale):
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-2, -1)
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B * T, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (1, 128, 3), (2, 256, 2), (1, 257, 2),
+                                   (1, 2001, 2), (1, 513, 1)])
+def test_attention_fwd_bwd(K, B, T, H):
+    scale = 0.125
+    qkv = bf(rnd(B * T, 3 * H * 64, scale=1.5, seed=19))
+    out, lse = K.attention_fwd(qkv, B, T, H, scale)
+    qr = qkv.float().requires_grad_(True)
+    ref, ref_lse = attn_ref(qr, B, T, H, scale)
+    close(out, ref, 8e-3, 4e-3, "attn.out")
+    close(lse, ref_lse, 1e-4, 2e-3, "attn.lse")
+    dout = bf(rnd(B * T, H * 64, seed=20))
+    ref.backward(dout.float())
+    dqkv = K.attention_bwd(qkv, out, dout, lse, B, T, H, scale)
+    g = qr.grad
+    # normalised max-abs (gradients span orders of magnitude): 1.5 % of the tensor's max
+    err = (dqkv.float() - g).abs().max().item()
+    assert err <= 1.5e-2 * g.abs().max().item(), f"attn.dqkv err {err:.3e} vs max {g.abs().max().item():.3e}"
+    cos = F.cosine_similarity(dqkv.float().flatten(), g.flatten(), dim=0).item()
+    assert cos > 0.9995, f"attn.dqkv cosine {cos}"
+
+
+def test_attention_online_softmax_rescale(K):
+    # a late key with a huge score forces the running-max rescale branch in a late chunk
+    B, T, H = 1, 201, 1
+    qkv = bf(rnd(B * T, 3 * 64, scale=0.5, seed=21)).view(T, 3, 64).clone()
+    qkv[190, 1] = qkv[5, 0] * 40          # key 190 aligned with query 5
+    qkv = qkv.view(T, 192).contiguous()
+    out, lse = K.attention_fwd(qkv, B, T, H, 0.125)
+    ref, ref_lse = attn_ref(qkv, B, T, H, 0.125)
+    close(out, ref, 8e-3, 4e-3, "attn.out(rescale)")
+    close(lse, ref_lse, 1e-4, 2e-3, "attn.lse(rescale)")
+
+
+def test_head_and_loss(K):
+    B_, N, D = 3, 50, 768
+    for out_dim in (1, 2):
+        hf = bf(rnd(B_ * (N + 1), D, seed=22))
+        W = rnd(out_dim, D, scale=0.05, seed=23)
+        b = rnd(out_dim, scale=0.1, seed=24) + 0.5
+        logits, pred = K.head_fwd(hf, W, b, B_, N)
+        hr = hf.float().view(B_, N + 1, D).requires_grad_(True)
+        Wr = W.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        refl = F.linear(hr[:, 1:], Wr, br)
+        refp = F.softplus(refl)
+        close(logits, refl, 1e-4, 1e-4, "head.logits")
+        close(pred, refp, 1e-4, 1e-4, "head.pred")
+        obs = rnd(B_, N, out_dim, seed=25).abs()
+        loss, gu = K.loss_fwd(K.LOSS_POISSON, pred.view(-1, out_dim), obs.view(-1, out_dim))
+        refloss = F.poisson_nll_loss(refp, obs, log_input=False)
+        close(loss, refloss, 1e-5, 1e-6, "poisson")
+        refloss.backward()
+        dpred = K.scale_by_scalar(gu, torch.ones((), device="cuda"), 1.0).view(B_, N, out_dim)
+        dh, dW, db = K.head_bwd(dpred, logits, hf, W, B_, N)
+        close(dh.view(B_, N + 1, D), hr.grad, 8e-3, 1e-7, "head.dh")
+        assert (dh.view(B_, N + 1, D)[:, 0] == 0).all()
+        close(dW, Wr.grad, 1e-3, 1e-5, "head.dW")
+        close(db, br.grad, 1e-3, 1e-6, "head.db")
+    # MSE with padded prediction rows
+    p = rnd(40, 288, seed=26)
+    o = rnd(40, 283, seed=27)
+    loss, gu = K.loss_fwd(K.LOSS_MSE, p[:, :283], o, weight=2.0)
+    pr = p[:, :283].clone().requires_grad_(True)
+    ref = F.mse_loss(pr, o)
+    ref.backward()
+    close(loss, 2.0 * ref, 1e-5, 1e-6, "mse")
+    close(gu, pr.grad, 1e-5, 1e-8, "mse.grad")
+
+
+def test_embed_bwd_prep_gather_colsum(K):
+    B_, N, D = 3, 40, 768
+    T = N + 1
+    dx0 = rnd(B_ * T, D, seed=28)
+    mask = (torch.rand(B_ * N, generator=torch.Generator().manual_seed(2)) < 0.5).cuda()
+    dz, dcls, dmt, dbias = K.embed_bwd_prep(dx0, mask.to(torch.uint8), B_, N, D)
+    v = dx0.view(B_, T, D)
+    reg = v[:, 1:].reshape(-1, D)
+    close(dcls, v[:, 0].sum(0), 1e-5, 1e-5, "dcls")
+    close(dmt, reg[mask].sum(0), 1e-5, 1e-4, "dmask_token")
+    close(dbias, reg[~mask].sum(0), 1e-5, 1e-4, "dbias")
+    assert torch.equal(dz, bf(torch.where(mask[:, None], torch.zeros_like(reg), reg)))
+    dz2, _, dmt2, dbias2 = K.embed_bwd_prep(dx0, None, B_, N, D)
+    assert torch.equal(dz2, bf(reg)) and (dmt2 == 0).all()
+    close(dbias2, reg.sum(0), 1e-5, 1e-4, "dbias-nomask")
+    # gather / scatter
+    src = bf(rnd(100, D, seed=29))
+    idx = torch.tensor([5, 0, 99, 42, 7], device="cuda")
+    gth = K.gather_rows(src, idx)
+    assert torch.equal(gth, src[idx])
+    sc = K.gather_rows(gth, idx, n_out=100, scatter=True)
+    ref = torch.zeros_like(src)
+    ref[idx] = src[idx]
+    assert torch.equal(sc, ref)
+    # column sums
+    X = bf(rnd(777, 2304, seed=30))
+    close(K.colsum_bf16(X), X.float().sum(0), 1e-4, 1e-3, "colsum")
+
+
+def test_errors_are_loud(K):
+    A = torch.zeros(8, 100, dtype=torch.bfloat16, device="cuda")   # K=100 not a multiple of 64
+    out = torch.empty(8, 8, dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        K.gemm_tn(K.EPI_F32, A, A[:8].contiguous(), out)
+    with pytest.raises(RuntimeError):
+        K.layernorm_fwd(torch.zeros(4, 100, device="cuda"), torch.zeros(100, device="cuda"), torch.zeros(100, device="cuda"))
+    with pytest.raises(RuntimeError, match="GPU"):
+        K.cast_pad(torch.zeros(4, 8))
