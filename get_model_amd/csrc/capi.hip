@@ -38,6 +38,9 @@ int getmi_gather_rows_impl(const bf16_t*, const int64_t*, bf16_t*, int, int, int
 size_t getmi_colsum_workspace_bytes_impl(int N);
 int getmi_colsum_bf16_impl(const bf16_t*, float*, int, int, int, int, void*, size_t, hipStream_t);
 
+size_t getmi_scale_cast_workspace_bytes_impl(int M, int D);
+int getmi_scale_cast_impl(const float*, const float*, int, bf16_t*, float*, int, int, int, void*, size_t, hipStream_t);
+
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 #define BF(p) reinterpret_cast<const bf16_t*>(p)
 #define BFW(p) reinterpret_cast<bf16_t*>(p)
@@ -130,5 +133,12 @@ size_t getmi_head_bwd_workspace_bytes(int B, int N, int D, int out_dim) {
 }
 size_t getmi_loss_workspace_bytes(void) { return getmi_loss_workspace_bytes_impl(); }
 size_t getmi_colsum_workspace_bytes(int N) { return getmi_colsum_workspace_bytes_impl(N); }
+
+size_t getmi_scale_cast_workspace_bytes(int M, int D) { return getmi_scale_cast_workspace_bytes_impl(M, D); }
+int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample, void* dz, float* dbias, int accumulate,
+                     int M, int D, void* workspace, size_t workspace_bytes, void* stream) {
+    return getmi_scale_cast_impl(dx, rowscale, rows_per_sample, BFW(dz), dbias, accumulate, M, D, workspace,
+                                 workspace_bytes, ST(stream));
+}
 
 }  // extern "C"

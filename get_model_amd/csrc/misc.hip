@@ -101,6 +101,35 @@ __global__ __launch_bounds__(256) void embed_bwd_prep_kernel(const float* __rest
     }
 }
 
+// ---- dz = bf16(rowscale[row/T] * dx) and its column sums (the gradient entering a residual branch:
+//      DropPath backward of model/transformer.py:247-248 + bias gradient of the branch's last Linear) ----
+template <int NV>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ dx, const float* __restrict__ rowscale,
+                                                         int rows_per_sample, bf16_t* __restrict__ dz,
+                                                         float* __restrict__ partial, int M) {
+    constexpr int D = NV * 256;
+    __shared__ __attribute__((aligned(16))) float red[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float sc = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 g = *reinterpret_cast<const float4*>(dx + (size_t)row * D + (v * 64 + lane) * 4);
+            g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+            *reinterpret_cast<uint2*>(dz + (size_t)row * D + (v * 64 + lane) * 4) = pack4bf(g.x, g.y, g.z, g.w);
+            acc[v].x += g.x; acc[v].y += g.y; acc[v].z += g.z; acc[v].w += g.w;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(&red[wave][(v * 64 + lane) * 4]) = acc[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+        partial[(size_t)blockIdx.x * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
 // ---- expression head: logits = hf[b, 1+n, :] . Wh^T + bh ; pred = softplus(logits)
 //      (model/model.py:575-576, model/modules.py:255-258; Softplus beta=1, threshold=20) ----
 template <int NV, int OUT>
@@ -324,6 +353,25 @@ int getmi_embed_bwd_prep_impl(const float* dx0, const uint8_t* mask, bf16_t* dz,
     }
     GETMI_CHECK_LAUNCH("embed_bwd_prep");
     return getmi_colreduce_impl(partial, dcls, dmask_token, dbias, g, D, accumulate, st);
+}
+
+size_t getmi_scale_cast_workspace_bytes_impl(int M, int D) { return (size_t)rows_grid(M) * D * sizeof(float); }
+
+int getmi_scale_cast_impl(const float* dx, const float* rowscale, int rows_per_sample, bf16_t* dz, float* dbias,
+                          int accumulate, int M, int D, void* ws, size_t ws_bytes, hipStream_t st) {
+    GETMI_CHECK_ARG(D == 768 || D == 256 || D == 512 || D == 1024, "scale_cast: D=%d unsupported", D);
+    GETMI_CHECK_ARG(M > 0 && (!rowscale || rows_per_sample > 0), "scale_cast: bad shape");
+    GETMI_CHECK_ARG(ws_bytes >= getmi_scale_cast_workspace_bytes_impl(M, D), "scale_cast: workspace too small");
+    const int g = rows_grid(M);
+    float* partial = reinterpret_cast<float*>(ws);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(scale_cast_kernel<1>, dim3(g), dim3(256), 0, st, dx, rowscale, rows_per_sample, dz, partial, M); break;
+        case 2: hipLaunchKernelGGL(scale_cast_kernel<2>, dim3(g), dim3(256), 0, st, dx, rowscale, rows_per_sample, dz, partial, M); break;
+        case 3: hipLaunchKernelGGL(scale_cast_kernel<3>, dim3(g), dim3(256), 0, st, dx, rowscale, rows_per_sample, dz, partial, M); break;
+        case 4: hipLaunchKernelGGL(scale_cast_kernel<4>, dim3(g), dim3(256), 0, st, dx, rowscale, rows_per_sample, dz, partial, M); break;
+    }
+    GETMI_CHECK_LAUNCH("scale_cast");
+    return getmi_colreduce_impl(partial, dbias, nullptr, nullptr, g, D, accumulate, st);
 }
 
 int getmi_head_fwd_impl(const bf16_t* hf, const float* W, const float* bias, float* logits, float* pred, int B, int N,

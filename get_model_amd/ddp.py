@@ -1,0 +1,117 @@
+"""Data-parallel gradient exchange for the GET region models: one process per GPU, bucketed all-reduce on
+RCCL (torch.distributed backend "nccl") overlapped with backward.
+
+Counterpart of the reference's Lightning `strategy="ddp_find_unused_parameters_true"` (utils.py:41-51): samples
+are split over ranks, weights are replicated, and the only exchange step of the path is the mean of the
+gradients.  Differences by design:
+  * gradients live in flat fp32 buckets laid out in REVERSE forward order (head -> block L-1 -> ... -> embed),
+    one bucket per encoder block (~28 MB at 12Lx768), so a bucket completes as soon as its block's fused
+    backward returns and its all-reduce runs on RCCL's stream under the remaining backward;
+  * `param.grad` are views into the buckets: no flatten/unflatten copies, and the optimizer reads the reduced
+    gradients in place;
+  * no unused-parameter graph walk: parameters that received no gradient are simply reduced as zeros.
+Works with any backend (`gloo` on CPU for the tests).
+"""
+import re
+
+import torch
+import torch.distributed as dist
+
+
+def _bucket_key(name):
+    m = re.match(r"encoder\.blocks\.(\d+)\.", name)
+    if m:
+        return ("block", int(m.group(1)))
+    if name.startswith("encoder.norm") or name.startswith("head"):
+        return ("head", 0)
+    return ("embed", 0)
+
+
+class GradBuckets:
+    """Flat gradient buckets + async all-reduce from post-accumulate-grad hooks."""
+
+    def __init__(self, module, process_group=None, bucket_cap_mb=64.0):
+        self.module = module
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        groups = {}
+        for n, p in named:
+            groups.setdefault(_bucket_key(n), []).append(p)
+        order = sorted(groups, key=lambda k: {"head": 0, "block": 1, "embed": 2}[k[0]] * 100000 - (k[1] if k[0] == "block" else 0))
+        # merge small neighbours up to the cap so tiny buckets (head, embed) do not cost a launch each
+        cap = int(bucket_cap_mb * 1024 * 1024 / 4)
+        self.buckets = []
+        cur, cur_n = [], 0
+        for k in order:
+            n = sum(p.numel() for p in groups[k])
+            if cur and cur_n + n > cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+            cur += groups[k]
+            cur_n += n
+        if cur:
+            self.buckets.append(cur)
+        self.flat = []
+        self._bucket_of = {}
+        self._pending = []
+        for bi, params in enumerate(self.buckets):
+            total = sum(p.numel() for p in params)
+            dev, dt = params[0].device, params[0].dtype
+            flat = torch.zeros(total, dtype=dt, device=dev)
+            off = 0
+            for p in params:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self._bucket_of[p] = bi
+            self.flat.append(flat)
+        self._remaining = [len(b) for b in self.buckets]
+        self._handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
+        self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+
+    # ---- per step ----
+    def zero_grad(self):
+        for f in self.flat:
+            f.zero_()
+        self._remaining = [len(b) for b in self.buckets]
+        self._handles = []
+
+    def _launch(self, bi):
+        if self.world == 1:
+            return
+        flat = self.flat[bi]
+        if self._use_avg:
+            self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+        else:
+            self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat))
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[p]
+        self._remaining[bi] -= 1
+        if self._remaining[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        """Call after backward: launches buckets whose parameters got no gradient (unused), then waits."""
+        for bi, r in enumerate(self._remaining):
+            if r > 0:
+                self._remaining[bi] = 0
+                self._launch(bi)
+        for h, flat in self._handles:
+            h.wait()
+            if flat is not None:
+                flat.div_(self.world)
+        self._handles = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """Make every rank start from rank `src`'s weights (what DDP does at construction)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=process_group)

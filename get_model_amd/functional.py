@@ -1,0 +1,317 @@
+"""Autograd operators of the GET region path, each one a sequence of libgetmi355 kernel launches.
+
+Granularity follows the reference's module boundaries (`region_embed`, `encoder.blocks.i`,
+`encoder.norm`+head must stay real submodules whose outputs are autograd tensors), fused *inside* them:
+
+  RegionEmbedTokens   model/modules.py:101-103 + model/model.py:520-525,571-573   (embed, mask blend, CLS)
+  EncoderBlock        model/transformer.py:240-248 (LN, qkv, attention, proj, residual, LN, MLP, residual)
+  FinalNorm           model/transformer.py:364
+  ExpressionHeadSoftplus   model/model.py:575-576
+  MaskedHead          model/model.py:527-528
+  FusedLoss           model/model.py:144-149 with PoissonNLLLoss / MSELoss
+
+Numerics: fp32 master weights and fp32 residual stream; bf16 MFMA operands with fp32 accumulation; bf16
+saved activations.  There is no eager fallback: CPU tensors raise.
+"""
+import torch
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("get_model_amd: the GET hot path runs only on an MI355X GPU (HIP kernels); got a CPU "
+                           "tensor and there is deliberately no CPU fallback")
+
+
+class _WeightCache:
+    """bf16 (and transposed bf16) copies of fp32 master weights, refreshed when the parameter changes
+    (in-place optimizer steps bump `_version`)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w, kind, make):
+        if not isinstance(w, torch.nn.Parameter):
+            return make(w)          # e.g. a LoRA-parametrised weight: new tensor every access
+        key = (id(w), kind)
+        hit = self._c.get(key)
+        tag = (w._version, w.data_ptr(), tuple(w.shape))
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        val = make(w.detach())
+        self._c[key] = (tag, val)
+        return val
+
+    def clear(self):
+        self._c.clear()
+
+
+WEIGHTS = _WeightCache()
+
+
+def w_bf16(w):
+    return WEIGHTS.get(w, "n", lambda t: K.cast_bf16(t.contiguous()))
+
+
+def w_bf16_t(w):
+    return WEIGHTS.get(w, "t", lambda t: K.cast_transpose(t.contiguous()))
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def w_bf16_kpad(w, kp):
+    """[N,K] fp32 -> bf16 [N,Kp] zero-padded along K."""
+    return WEIGHTS.get(w, ("kpad", kp), lambda t: K.cast_pad(t.contiguous(), kp))
+
+
+# --------------------------------------------------------------------------------------------
+class RegionEmbedTokens(torch.autograd.Function):
+    """tokens[B,N+1,D] fp32 = cat(cls, where(mask, mask_token, region_motif @ W^T + b))."""
+
+    @staticmethod
+    def forward(ctx, region_motif, weight, bias, cls_token, mask_token, mask):
+        _need_gpu(region_motif)
+        B, N, Fin = region_motif.shape
+        D = weight.shape[0]
+        Kp = _pad_to(Fin, 64)
+        a = K.cast_pad(region_motif.detach().reshape(B * N, Fin).contiguous().float(), Kp)
+        wb = w_bf16_kpad(weight, Kp)
+        mask_u8 = None if mask is None else mask.reshape(B * N).to(torch.uint8).contiguous()
+        x0 = torch.empty(B, N + 1, D, dtype=torch.float32, device=region_motif.device)
+        K.gemm_tn(K.EPI_EMBED, a, wb, x0, bias=bias.detach().contiguous(), mask=mask_u8,
+                  mask_token=None if mask_token is None else mask_token.detach().reshape(D).contiguous(),
+                  regions_per_sample=N)
+        K.fill_cls(x0, cls_token.detach().reshape(D).contiguous(), B, N + 1, D)
+        ctx.save_for_backward(a, mask_u8)
+        ctx.dims = (B, N, Fin, D, Kp)
+        ctx.has_mask_token = mask_token is not None
+        ctx.weight = weight
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        a, mask_u8 = ctx.saved_tensors
+        B, N, Fin, D, Kp = ctx.dims
+        dz, dcls, dmt, dbias = K.embed_bwd_prep(dx0.contiguous(), mask_u8, B, N, D)
+        dW = dIn = None
+        if ctx.needs_input_grad[1]:
+            dW = K.gemm_wgrad(dz, a)[:, :Fin]          # [D, Kp] -> [D, Fin]
+        if ctx.needs_input_grad[0]:
+            # d(region_motif) = dz @ W   (interpretation / Jacobian use; not on the training path)
+            wt = K.cast_pad(ctx.weight.detach().t().contiguous(), _pad_to(D, 64))     # [Fin, D]
+            fin_p = _pad_to(Fin, 4)
+            if fin_p != Fin:
+                wt = torch.cat([wt, wt.new_zeros(fin_p - Fin, wt.shape[1])], 0)
+            out = torch.empty(B * N, fin_p, dtype=torch.float32, device=dz.device)
+            K.gemm_tn(K.EPI_F32, dz, wt, out)
+            dIn = out[:, :Fin].reshape(B, N, Fin)
+        return (dIn, dW, dbias if ctx.needs_input_grad[2] else None,
+                dcls.view(1, 1, D) if ctx.needs_input_grad[3] else None,
+                dmt.view(1, 1, D) if (ctx.has_mask_token and ctx.needs_input_grad[4]) else None, None)
+
+
+# --------------------------------------------------------------------------------------------
+class EncoderBlock(torch.autograd.Function):
+    """One pre-LN transformer block on the fp32 residual stream x[B,T,D].
+
+    scale1 / scale2: per-sample DropPath factors keep/keep_prob ([B] fp32) or None (identity)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
+                scale1, scale2, num_heads, eps):
+        _need_gpu(x)
+        B, T, D = x.shape
+        M = B * T
+        H = num_heads
+        if D != H * 64:
+            raise RuntimeError(f"get_model_amd attention kernel needs head_dim 64 (embed_dim {D}, heads {H})")
+        dev = x.device
+        x2 = x.detach().reshape(M, D).contiguous()
+        att_scale = 64 ** -0.5
+        # --- attention branch ---
+        h1, mean1, rstd1 = K.layernorm_fwd(x2, n1w.detach(), n1b.detach(), eps)
+        qkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, h1, w_bf16(qkv_w), qkv, bias=K.qkv_bias(q_bias.detach(), v_bias.detach()))
+        a, lse = K.attention_fwd(qkv, B, T, H, att_scale)
+        x_mid = torch.empty(M, D, dtype=torch.float32, device=dev)
+        K.gemm_tn(K.EPI_BIAS_RESID, a, w_bf16(proj_w), x_mid, bias=proj_b.detach(), resid=x2, rowscale=scale1,
+                  rows_per_sample=T)
+        # --- MLP branch ---
+        h2, mean2, rstd2 = K.layernorm_fwd(x_mid, n2w.detach(), n2b.detach(), eps)
+        Fh = fc1_w.shape[0]
+        u = torch.empty(M, Fh, dtype=BF16, device=dev)
+        g = torch.empty(M, Fh, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BIAS_GELU, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach())
+        x_out = torch.empty(M, D, dtype=torch.float32, device=dev)
+        K.gemm_tn(K.EPI_BIAS_RESID, g, w_bf16(fc2_w), x_out, bias=fc2_b.detach(), resid=x_mid, rowscale=scale2,
+                  rows_per_sample=T)
+        ctx.save_for_backward(x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2,
+                              n1w, n2w)
+        ctx.weights = (qkv_w, proj_w, fc1_w, fc2_w)
+        ctx.dims = (B, T, D, H, att_scale)
+        return x_out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dx_out):
+        (x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2, n1w, n2w) = ctx.saved_tensors
+        qkv_w, proj_w, fc1_w, fc2_w = ctx.weights
+        B, T, D, H, att_scale = ctx.dims
+        M = B * T
+        dev = dx_out.device
+        need = ctx.needs_input_grad
+        dx_out = dx_out.reshape(M, D).contiguous()
+        # ---- MLP branch ----
+        dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+        du = torch.empty_like(u)
+        K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u)               # (dz2 @ W2) * gelu'(u)
+        dfc2_w = K.gemm_wgrad(dz2, g) if need[12] else None
+        dh2 = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
+        dfc1_w = K.gemm_wgrad(du, h2) if need[10] else None
+        dfc1_b = K.colsum_bf16(du) if need[11] else None
+        dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
+                                                           rowscale=scale1, rows_per_sample=T, want_dz=True,
+                                                           want_dbias=True)
+        # ---- attention branch ----
+        da = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, dz1, w_bf16_t(proj_w), da)                       # dz1 @ Wproj
+        dproj_w = K.gemm_wgrad(dz1, a) if need[6] else None
+        dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
+        dh1 = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
+        dqkv_w = K.gemm_wgrad(dqkv, h1) if need[3] else None
+        dq_bias = dv_bias = None
+        if need[4] or need[5]:
+            dqb = K.colsum_bf16(dqkv)
+            dq_bias, dv_bias = dqb[:D], dqb[2 * D:]
+        dx_in, _, dn1w, dn1b, _ = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid)
+        return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
+                dfc1_b, dfc2_w, dfc2_b, None, None, None, None)
+
+
+# --------------------------------------------------------------------------------------------
+class FinalNorm(torch.autograd.Function):
+    """encoder.norm: fp32 tokens -> bf16 normalised tokens (consumed by the heads)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _need_gpu(x)
+        B, T, D = x.shape
+        x2 = x.detach().reshape(B * T, D).contiguous()
+        y, mean, rstd = K.layernorm_fwd(x2, w.detach(), b.detach(), eps)
+        ctx.save_for_backward(x2, mean, rstd, w)
+        ctx.dims = (B, T, D)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        B, T, D = ctx.dims
+        dy = dy.reshape(B * T, D)
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dx, _, dw, db, _ = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach())
+        return dx.view(B, T, D), dw, db, None
+
+
+class ExpressionHeadSoftplus(torch.autograd.Function):
+    """pred[B,N,out] = softplus(hf[:, 1:] @ W^T + b) on bf16 normalised tokens hf[B,N+1,D]."""
+
+    @staticmethod
+    def forward(ctx, hf, W, b):
+        _need_gpu(hf)
+        B, T, D = hf.shape
+        hf2 = hf.detach().reshape(B * T, D).contiguous()
+        Wd = W.detach().contiguous()
+        logits, pred = K.head_fwd(hf2, Wd, b.detach().contiguous(), B, T - 1)
+        ctx.save_for_backward(hf2, logits, Wd)
+        ctx.dims = (B, T, D)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        hf2, logits, Wd = ctx.saved_tensors
+        B, T, D = ctx.dims
+        dh, dW, db = K.head_bwd(dpred.contiguous().float(), logits, hf2, Wd, B, T - 1)
+        return dh.view(B, T, D), dW, db
+
+
+class MaskedHead(torch.autograd.Function):
+    """x_masked[n_masked, out] = hf[:, 1:][mask] @ W^T + b   (row order = torch boolean indexing order)."""
+
+    @staticmethod
+    def forward(ctx, hf, W, b, mask):
+        _need_gpu(hf)
+        B, T, D = hf.shape
+        N = T - 1
+        out_dim = W.shape[0]
+        m = mask.reshape(B, N)
+        flat = torch.nonzero(m.reshape(-1), as_tuple=False).squeeze(1)     # host sync: output shape is data dependent
+        idx = (flat // N) * T + 1 + (flat % N)
+        n = idx.numel()
+        hf2 = hf.detach().reshape(B * T, D).contiguous()
+        Np = _pad_to(out_dim, 4)
+        ctx.dims = (B, T, D, out_dim, n)
+        if n == 0:
+            ctx.save_for_backward(idx, hf2, W)
+            return torch.zeros(0, out_dim, dtype=torch.float32, device=hf.device)
+        hsel = K.gather_rows(hf2, idx)
+        wp = torch.zeros(Np, D, dtype=torch.float32, device=hf.device)
+        wp[:out_dim] = W.detach()
+        bp = torch.zeros(Np, dtype=torch.float32, device=hf.device)
+        bp[:out_dim] = b.detach()
+        out = torch.empty(n, Np, dtype=torch.float32, device=hf.device)
+        K.gemm_tn(K.EPI_F32, hsel, K.cast_bf16(wp), out, bias=bp)
+        ctx.save_for_backward(idx, hsel, W)
+        return out[:, :out_dim]
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, hsel, W = ctx.saved_tensors
+        B, T, D, out_dim, n = ctx.dims
+        dev = dout.device
+        if n == 0:
+            return (torch.zeros(B, T, D, dtype=BF16, device=dev), torch.zeros_like(W),
+                    torch.zeros(out_dim, dtype=torch.float32, device=dev), None)
+        Kp = _pad_to(out_dim, 64)
+        dop = K.cast_pad(dout.contiguous().float(), Kp)                       # [n, Kp] bf16
+        wtp = torch.zeros(D, Kp, dtype=torch.float32, device=dev)
+        wtp[:, :out_dim] = W.detach().t()
+        dhsel = torch.empty(n, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, dop, K.cast_bf16(wtp), dhsel)                    # dout @ W
+        dW = K.gemm_wgrad(dop, hsel)[:out_dim]
+        db = K.colsum_bf16(dop)[:out_dim]
+        dh = K.gather_rows(dhsel, idx, n_out=B * T, scatter=True)
+        return dh.view(B, T, D), dW, db, None
+
+
+class FusedLoss(torch.autograd.Function):
+    """weight * mean-reduced Poisson NLL (log_input=False, full=False) or MSE; forward also produces the
+    gradient, backward only scales it by the (device-resident) upstream scalar."""
+
+    @staticmethod
+    def forward(ctx, pred, obs, kind, weight, eps):
+        _need_gpu(pred)
+        C = pred.shape[-1]
+        p2 = pred.detach().reshape(-1, C)
+        o2 = obs.detach().to(torch.float32).reshape(-1, C)
+        if p2.stride(-1) != 1:
+            p2 = p2.contiguous()
+        if o2.stride(-1) != 1:
+            o2 = o2.contiguous()
+        loss, grad = K.loss_fwd(kind, p2, o2, weight=float(weight), eps=eps)
+        ctx.save_for_backward(grad)
+        ctx.weight = float(weight)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        d = K.scale_by_scalar(grad, gout.contiguous().float(), ctx.weight)
+        return d.view(ctx.shape), None, None, None, None

@@ -195,6 +195,17 @@ def scale_by_scalar(x, scalar, weight=1.0):
     return out
 
 
+def scale_cast(dx, rowscale=None, rows_per_sample=0):
+    """dx fp32 [M,D] -> (dz bf16 = rowscale*dx, dbias [D] = column sums of dz)."""
+    _chk(dx, rowscale)
+    M, D = dx.shape
+    dz = torch.empty(M, D, dtype=BF16, device=dx.device)
+    dbias = torch.empty(D, dtype=F32, device=dx.device)
+    ws = _ws(lib.query("getmi_scale_cast_workspace_bytes", M, D), dx.device)
+    lib.call("getmi_scale_cast", dx, rowscale, rows_per_sample, dz, dbias, 0, M, D, ws, ws.numel())
+    return dz, dbias
+
+
 def gather_rows(src, idx, n_out=None, scatter=False):
     """gather: dst[i] = src[idx[i]]; scatter: dst[idx[i]] = src[i] (dst zero-initialised, n_out rows)."""
     _chk(src, idx)

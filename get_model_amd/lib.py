@@ -39,6 +39,8 @@ _SIGNATURES = {
     "getmi_loss_workspace_bytes": (_sz, []),
     "getmi_loss_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp]),
     "getmi_scale_by_scalar": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
+    "getmi_scale_cast_workspace_bytes": (_sz, [_i, _i]),
+    "getmi_scale_cast": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "getmi_gather_rows_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "getmi_colsum_workspace_bytes": (_sz, [_i]),
     "getmi_colsum_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -98,6 +98,12 @@ int getmi_loss_fwd(int kind, const float* pred, const float* obs, float* loss, f
 int getmi_scale_by_scalar(const float* in, const float* scalar_dev, float weight, float* out, int64_t n,
                           void* stream);
 
+/* ---- gradient entering a residual branch: dz = bf16(rowscale[row/rows_per_sample]*dx), dbias = colsum(dz)
+ *      (autograd of `x + drop_path(branch)`, model/transformer.py:247-248) ----------------------------- */
+size_t getmi_scale_cast_workspace_bytes(int M, int D);
+int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample, void* dz_bf16, float* dbias,
+                     int accumulate, int M, int D, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- masked-row gather/scatter (model/model.py:527,535), column sums (bias gradients) ----------- */
 int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int D, int scatter,
                            void* stream);

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 (gloo): bucketed gradient all-reduce equals the single-process gradient of the mean loss."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.region_embed = nn.Linear(5, 8)
+        self.encoder = nn.Module()
+        self.encoder.blocks = nn.ModuleList([nn.Linear(8, 8) for _ in range(3)])
+        self.encoder.norm = nn.LayerNorm(8)
+        self.head_exp = nn.Linear(8, 2)
+        self.unused = nn.Parameter(torch.zeros(3))
+
+    def forward(self, x):
+        x = self.region_embed(x)
+        for b in self.encoder.blocks:
+            x = x + torch.tanh(b(x))
+        return self.head_exp(self.encoder.norm(x))
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    from get_model_amd.ddp import GradBuckets, broadcast_parameters
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)       # different init per rank: broadcast must fix it
+    m = Tiny()
+    broadcast_parameters(m)
+    gb = GradBuckets(m, bucket_cap_mb=0.0001)     # tiny cap -> several buckets
+    assert len(gb.buckets) >= 4
+    torch.manual_seed(0)
+    x = torch.randn(8, 5)
+    y = torch.randn(8, 2)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    for _ in range(2):                   # two steps: zero_grad must reset the buckets
+        gb.zero_grad()
+        ((m(xs) - ys) ** 2).mean().backward()
+        gb.finish()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    if rank == 0:
+        torch.save(({n: p.detach().clone() for n, p in m.named_parameters()}, grads, x, y), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_single_process(tmp_path):
+    ctx = mp.get_context("spawn")
+    out_path = str(tmp_path / "rank0.pt")
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    params, grads, x, y = torch.load(out_path, weights_only=True)
+    m = Tiny()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(params[n])
+    # mean over ranks of per-rank mean losses == DDP semantics
+    loss = 0.5 * (((m(x[:4]) - y[:4]) ** 2).mean() + ((m(x[4:]) - y[4:]) ** 2).mean())
+    loss.backward()
+    for n, p in m.named_parameters():
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(grads[n], ref, atol=1e-6), n
