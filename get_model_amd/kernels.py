@@ -11,6 +11,27 @@ EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_EMBED, EPI_F32 = range(6
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+# bench.py sets PROFILE = [] to collect (kernel name, algorithmic flops, start event, end event) per GEMM launch,
+# recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+_EPI_NAMES = ("bf16", "bias_gelu", "bias_resid", "dgelu", "embed", "f32")
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, name, flops):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((name, flops, e0, e1))
+
 
 def _chk(*ts):
     for t in ts:
@@ -66,9 +87,11 @@ def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, ro
     K = A.shape[1]
     N = B.shape[0]
     assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
+    e0 = _prof_begin()
     lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, out0.shape[-1], bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
              regions_per_sample)
+    _prof_end(e0, "gemm_tn_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K)
     return out0
 
 
@@ -83,7 +106,9 @@ def gemm_wgrad(X, Y, out=None, accumulate=False):
         accumulate = False
     nbytes = lib.query("getmi_gemm_wgrad_workspace_bytes", M, N1, N2)
     ws = _ws(nbytes, X.device)
+    e0 = _prof_begin()
     lib.call("getmi_gemm_wgrad", X, Y, M, N1, N2, X.stride(0), Y.stride(0), out, int(accumulate), ws, ws.numel())
+    _prof_end(e0, "gemm_wgrad_kernel(+reduce_slabs)", 2.0 * M * N1 * N2)
     return out
 
 
@@ -120,7 +145,9 @@ def attention_fwd(qkv, B, T, H, scale):
     _chk(qkv)
     out = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=F32, device=qkv.device)
+    e0 = _prof_begin()
     lib.call("getmi_attention_fwd", qkv, out, lse, B, T, H, float(scale))
+    _prof_end(e0, "attn_fwd_kernel", 4.0 * B * H * T * T * 64)
     return out, lse
 
 
@@ -128,7 +155,9 @@ def attention_bwd(qkv, out, dout, lse, B, T, H, scale):
     _chk(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)
     ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
+    e0 = _prof_begin()
     lib.call("getmi_attention_bwd", qkv, out, dout, lse, dqkv, B, T, H, float(scale), ws, ws.numel())
+    _prof_end(e0, "attn_bwd_kernel(+delta)", 10.0 * B * H * T * T * 64)
     return dqkv
 
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.golden_util import check_against_golden, golden_names, load_case
+from tests.golden_util import check_against_golden, golden_names, grouped, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -50,9 +50,10 @@ def test_hip_path_matches_reference_golden_and_oracle(name):
     torch.set_num_threads(16)
     oloss, opred, ograds = O.loss_and_grads(c["kind"], c["sd"], c["batch"], num_layers=c["L"], keep_masks=c["keep"])
     min_cos = 1.0
-    for n, g in grads.items():
-        ref = ograds[n].flatten()
-        cos = F.cosine_similarity(g.detach().float().cpu().flatten(), ref, dim=0).item()
+    gg, og = grouped(grads), grouped(ograds)
+    for n, g in gg.items():
+        ref = og[n]
+        cos = F.cosine_similarity(g, ref, dim=0).item()
         min_cos = min(min_cos, cos)
         assert cos >= 0.995, f"{n}: cosine vs oracle {cos}"
     perr = (pred.cpu() - opred).abs().max().item() / opred.abs().max().item()
