@@ -49,10 +49,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact (erf) GELU and its derivative, fp32
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact (erf) GELU and its derivative, fp32.  Phi(x) = 0.5*erfc(-x/sqrt2) through Abramowitz-Stegun 7.1.26
+// (|abs error of erf| <= 1.5e-7, far below the bf16 rounding of the stored result): one v_rcp + one v_exp.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& pdf) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float tail = 0.5f * poly * t * e;          // 0.5*erfc(|x|/sqrt2)
+    Phi = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float Phi, pdf;
+    gelu_parts(x, Phi, pdf);
+    return x * Phi;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float Phi, pdf;
+    gelu_parts(x, Phi, pdf);
+    return fmaf(x, pdf, Phi);
 }
 
 // ---- host side error channel (thread-local message, C-ABI returns an int code) ----

@@ -13,6 +13,7 @@
 // XOR-swizzled image (conflict-free ds_read_b128 / ds_read_b64_tr_b16), two LDS buffers, one barrier per
 // K-step, XCD-aware tile order.
 #include "common.h"
+#include <stdlib.h>
 
 enum {
     EPI_BF16 = 0,         // out0(bf16) = acc (+bias)
@@ -47,43 +48,95 @@ struct GemmArgs {
 #define TILE_BYTES (128 * 128)          // 128 rows x 64 bf16
 #define GEMM_LDS (4 * TILE_BYTES)       // 2 buffers x (A + B)
 
-template <int EPI>
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 v) {
-    // v = C[m][n..n+3]
-    if (m >= p.M || n >= p.N) return;
-    if (EPI == EPI_BF16 || EPI == EPI_F32 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_EMBED) {
-        if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
+// Epilogue of one wave's MT x NT grid of 16x16 accumulator tiles.  acc[mt][nt] holds C[em + 16*mt][en + 16*nt .. +3]
+// (row = lane&15, 4 consecutive columns per lane).  All global LOADS (bias, residual, pre-activation, row scale)
+// are issued first from clamped addresses -- no predication, one latency exposure per tile instead of one per
+// sub-tile -- then the arithmetic and the predicated stores.
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[MT][NT], int em, int en) {
+    float4 bv[NT];
+    const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(en + nt * 16, p.N - 4);
+        bv[nt] = has_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (EPI == EPI_BF16) {
-        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
-    } else if (EPI == EPI_F32) {
-        *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-    } else if (EPI == EPI_BIAS_GELU) {
-        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) =
-            pack4bf(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
-    } else if (EPI == EPI_BIAS_RESID) {
-        const float s = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
-        const float4 r = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + n);
-        *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) =
-            make_float4(r.x + s * v[0], r.y + s * v[1], r.z + s * v[2], r.w + s * v[3]);
-    } else if (EPI == EPI_DGELU) {
-        const uint2 u = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
-        const float u0 = bf2f(u.x & 0xffff), u1 = bf2f(u.x >> 16), u2 = bf2f(u.y & 0xffff), u3 = bf2f(u.y >> 16);
-        *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) =
-            pack4bf(v[0] * dgelu_f(u0), v[1] * dgelu_f(u1), v[2] * dgelu_f(u2), v[3] * dgelu_f(u3));
-    } else if (EPI == EPI_EMBED) {
-        const int b = m / p.regions_per_sample, r = m - b * p.regions_per_sample;
-        const size_t orow = (size_t)b * (p.regions_per_sample + 1) + 1 + r;
-        if (p.mask && p.mask[m]) {
-            const float4 t = *reinterpret_cast<const float4*>(p.mask_token + n);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    if (EPI == EPI_BIAS_RESID) {
+        float4 rv[MT][NT];
+        float sc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(em + mt * 16, p.M - 1);
+            sc[mt] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                rv[mt][nt] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + nt * 16, p.N - 4));
         }
-        *reinterpret_cast<float4*>((float*)p.out0 + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int m = em + mt * 16, n = en + nt * 16;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = acc[mt][nt];
+                    const float4 r = rv[mt][nt], b = bv[nt];
+                    const float s = sc[mt];
+                    *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) =
+                        make_float4(r.x + s * (v[0] + b.x), r.y + s * (v[1] + b.y), r.z + s * (v[2] + b.z),
+                                    r.w + s * (v[3] + b.w));
+                }
+            }
+        return;
     }
+    if (EPI == EPI_DGELU) {
+        uint2 uv[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                uv[mt][nt] = *reinterpret_cast<const uint2*>(p.aux + (size_t)min(em + mt * 16, p.M - 1) * p.ldaux +
+                                                             min(en + nt * 16, p.N - 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int m = em + mt * 16, n = en + nt * 16;
+                if (m < p.M && n < p.N) {
+                    const f32x4 v = acc[mt][nt];
+                    const uint2 u = uv[mt][nt];
+                    *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) =
+                        pack4bf(v[0] * dgelu_f(bf2f(u.x & 0xffff)), v[1] * dgelu_f(bf2f(u.x >> 16)),
+                                v[2] * dgelu_f(bf2f(u.y & 0xffff)), v[3] * dgelu_f(bf2f(u.y >> 16)));
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = em + mt * 16, n = en + nt * 16;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = acc[mt][nt];
+            v[0] += bv[nt].x; v[1] += bv[nt].y; v[2] += bv[nt].z; v[3] += bv[nt].w;
+            if (EPI == EPI_BF16) {
+                *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
+            } else if (EPI == EPI_F32) {
+                *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (EPI == EPI_BIAS_GELU) {
+                *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) =
+                    pack4bf(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+            } else if (EPI == EPI_EMBED) {
+                const int b = m / p.regions_per_sample, r = m - b * p.regions_per_sample;
+                const size_t orow = (size_t)b * (p.regions_per_sample + 1) + 1 + r;
+                if (p.mask && p.mask[m]) {
+                    const float4 t = *reinterpret_cast<const float4*>(p.mask_token + n);
+                    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                }
+                *reinterpret_cast<float4*>((float*)p.out0 + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -167,10 +220,165 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
 
     const int em = m0 + wr * 64 + (lane & 15);
     const int en = n0 + wc * 64 + (lane >> 4) * 4;
+    epilogue_tiles<EPI, 4, 4>(p, acc, em, en);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn, large-tile pipeline: 256x256 output tile, BK=64, 8 waves (2 M x 4 N, 128x64 per wave), ONE
+// workgroup per CU (128 KiB LDS: two K-tile buffers of A[256][64] + B[256][64]).
+//
+// A K-tile is consumed in four phases, one 64x32 quadrant of the wave's output each (16 MFMAs):
+//     P1 (rows 0-63 , cols 0-31 ) reads A-half0 + B-half0 fragments      P2 (rows 0-63 , cols 32-63) reads B-half1
+//     P3 (rows 64-127, cols 32-63) reads A-half1                          P4 (rows 64-127, cols 0-31 ) reads nothing
+// and is STAGED as four half-tiles of 16 KiB in the order they are needed (A0, B0, B1, A1).  Half-tile q
+// (= 4*tile + j) is issued in phase q-7, i.e. ~1.75 K-tiles (5 half-tiles = 80 KiB per CU) stay in flight
+// across barriers; each reading phase waits with a COUNTED `s_waitcnt vmcnt(10)` (never 0 in steady state)
+// and one raw s_barrier.  Hazards (all waves pass the same barriers):
+//   RAW: phase phi needs half-tiles <= phi+1; every wave waits for its own share (vmcnt) before the barrier.
+//   WAR: half-tile q overwrites the slot of q-8, whose last read was in phase q-8 (A0,B0), q-9 (B1: read in
+//        P2 = phase q-8... ) -- in all four cases at least one barrier lies between that read phase and
+//        phase q-7, and a wave reaches a barrier only after its MFMAs consumed the fragments it read.
+// ------------------------------------------------------------------------------------------------
+#define G2_LDS 131072
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// wait until at most `halftiles` of this wave's youngest half-tile loads (2 instructions each) are pending
+__device__ __forceinline__ void wait_halftiles(int halftiles) {
+    if (halftiles >= 5) wait_vmcnt<10>();
+    else if (halftiles == 4) wait_vmcnt<8>();
+    else if (halftiles == 3) wait_vmcnt<6>();
+    else if (halftiles == 2) wait_vmcnt<4>();
+    else if (halftiles == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+__device__ __forceinline__ void phase_barrier() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tiles_n = (p.N + 255) >> 8;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int m0 = tm << 8, n0 = tn << 8;
+    const int nk = p.K >> 6;
+    const int nq = nk << 2;   // number of half-tiles
+
+    // ---- staging set-up: kind j = 0:A-half0 1:B-half0 2:B-half1 3:A-half1 ; 2 wave-instructions per kind ----
+    const char* src[4][2];
+    int dst[4][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) epilogue4<EPI>(p, em + mt * 16, en + nt * 16, acc[mt][nt]);
+        for (int jj = 0; jj < 2; ++jj) {
+            const int hr0 = (wave * 2 + jj) * 8;          // wave-uniform first half-row of this instruction
+            const int hr = hr0 + (lane >> 3);
+            int row, row0;
+            if (j == 0 || j == 3) {
+                const int h = (j == 3);
+                row = ((hr >> 6) << 7) + h * 64 + (hr & 63);
+                row0 = ((hr0 >> 6) << 7) + h * 64 + (hr0 & 63);
+                const int g = min(m0 + row, p.M - 1);
+                src[j][jj] = reinterpret_cast<const char*>(p.A + (size_t)g * p.lda) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                dst[j][jj] = row0 * 128;
+            } else {
+                const int h = j - 1;
+                row = ((hr >> 5) << 6) + h * 32 + (hr & 31);
+                row0 = ((hr0 >> 5) << 6) + h * 32 + (hr0 & 31);
+                const int g = min(n0 + row, p.N - 1);
+                src[j][jj] = reinterpret_cast<const char*>(p.B + (size_t)g * p.ldb) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                dst[j][jj] = 32768 + row0 * 128;
+            }
+        }
+    // issue half-tile (tile t, kind J)
+#define G2_ISSUE(t, J)                                                                         \
+    do {                                                                                       \
+        char* b_ = smem + (((t)&1) << 16);                                                     \
+        glds16(src[J][0] + (size_t)(t) * 128, b_ + dst[J][0]);                                 \
+        glds16(src[J][1] + (size_t)(t) * 128, b_ + dst[J][1]);                                 \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 128 + (((4 * ks + (lane >> 4)) ^ fsw) << 4);
+    const int a_base = (wm * 128) * 128;                 // + mh*64*128 + mt*16*128
+    const int b_base = 32768 + (wn * 64) * 128;          // + nh*32*128 + nt*16*128
+
+    // ---- prologue: half-tiles 0..6 ----
+    G2_ISSUE(0, 0); G2_ISSUE(0, 1); G2_ISSUE(0, 2); G2_ISSUE(0, 3);
+    if (nk > 1) { G2_ISSUE(1, 0); G2_ISSUE(1, 1); G2_ISSUE(1, 2); }
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define G2_LOAD_A(MH)                                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        fa[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + ((MH)*64 + mt * 16) * 128 + foff[ks]);
+#define G2_LOAD_B(FB, NH)                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        FB[nt][ks] = *reinterpret_cast<const bf16x8*>(buf + b_base + ((NH)*32 + nt * 16) * 128 + foff[ks]);
+#define G2_MMA(MH, NH, FB)                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
+            acc[(MH)*4 + mt][(NH)*2 + nt] =                                                                \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt][ks], fa[mt][ks], acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
+
+    for (int s = 0; s < nk; ++s) {
+        const char* buf = smem + ((s & 1) << 16);
+        const int phi = s << 2;
+        // issued before phase phi: half-tiles <= min(phi+6, nq-1); needed: <= phi+1
+        // ---- P1 ----
+        wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
+        phase_barrier();
+        G2_LOAD_A(0)
+        G2_LOAD_B(fb0, 0)
+        if (s + 1 < nk) G2_ISSUE(s + 1, 3);
+        G2_MMA(0, 0, fb0)
+        // ---- P2 ----
+        wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
+        phase_barrier();
+        G2_LOAD_B(fb1, 1)
+        if (s + 2 < nk) G2_ISSUE(s + 2, 0);
+        G2_MMA(0, 1, fb1)
+        // ---- P3 ----
+        wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
+        phase_barrier();
+        G2_LOAD_A(1)
+        if (s + 2 < nk) G2_ISSUE(s + 2, 1);
+        G2_MMA(1, 1, fb1)
+        // ---- P4 (no new data, no barrier) ----
+        if (s + 2 < nk) G2_ISSUE(s + 2, 2);
+        G2_MMA(1, 0, fb0)
+    }
+#undef G2_ISSUE
+#undef G2_LOAD_A
+#undef G2_LOAD_B
+#undef G2_MMA
+
+    const int em = m0 + wm * 128 + (lane & 15);
+    const int en = n0 + wn * 64 + (lane >> 4) * 4;
+    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), em, en);
+    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), em + 64, en);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,8 +538,35 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 // ------------------------------------------------------------------------------------------------
 // host launchers (internal C++ API used by capi.hip)
 // ------------------------------------------------------------------------------------------------
+// tile selection: 0 = auto, 1 = force 128x128, 2 = force 256x256 (set from GETMI_GEMM_TILE for benchmarking)
+static int g_tile_mode = -1;
+static bool use_big_tile(const GemmArgs& a) {
+    if (g_tile_mode < 0) {
+        const char* e = getenv("GETMI_GEMM_TILE");
+        g_tile_mode = e ? atoi(e) : 0;
+    }
+    if (g_tile_mode == 1) return false;
+    if (g_tile_mode == 2) return true;
+    return a.M >= 2048 && a.N >= 512;
+}
+
+template <int EPI>
+static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    const int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL(gemm_tn256_kernel<EPI>, dim3(grid), dim3(512), G2_LDS, st, a);
+    GETMI_CHECK_LAUNCH("gemm_tn256");
+    return GETMI_OK;
+}
+
 template <int EPI>
 static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
+    if (use_big_tile(a)) return launch_gemm_tn256<EPI>(a, st);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<EPI>),
@@ -378,7 +613,8 @@ int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
 int getmi_wgrad_nsplit(int M, int N1, int N2) {
     const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
     const int nk = (M + BK - 1) / BK;
-    int want = (512 + ntile - 1) / ntile;
+    // one full wave of blocks at 2 blocks/CU (512 slots): never spill a few blocks into a second round
+    int want = 512 / ntile;
     if (want < 1) want = 1;
     if (want > nk) want = nk;
     if (want > 64) want = 64;

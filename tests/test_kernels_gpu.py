@@ -49,7 +49,10 @@ def test_cast_and_transpose(K):
 
 
 @pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (201, 768, 768), (804, 2304, 768), (333, 3072, 768),
-                                    (402, 768, 3072), (1000, 768, 320)])
+                                    (402, 768, 3072), (1000, 768, 320),
+                                    # M >= 2048 and N >= 512 select the 256x256 deep-pipelined kernel
+                                    (2048, 512, 64), (2304, 768, 768), (2500, 2304, 128), (2049, 768, 3072),
+                                    (4000, 516, 320), (6030, 3072, 768)])
 def test_gemm_tn_plain_asymmetric(K, M, N, K_):
     # asymmetric integer-valued operands: exact in bf16/fp32, catches any row/col or k-order mix-up
     A = ((torch.arange(M * K_).reshape(M, K_) * 7 + 3) % 13 - 6).float().cuda()
@@ -63,8 +66,9 @@ def test_gemm_tn_plain_asymmetric(K, M, N, K_):
     assert torch.equal(outb, bf(ref))
 
 
-def test_gemm_tn_epilogues(K):
-    M, N, K_, T = 402, 768, 768, 201
+@pytest.mark.parametrize("M", [402, 2211])
+def test_gemm_tn_epilogues(K, M):
+    N, K_, T = 768, 768, 201
     A, W = bf(rnd(M, K_, seed=4)), bf(rnd(N, K_, scale=0.05, seed=5))
     bias = rnd(N, scale=0.1, seed=6)
     ref = A.float() @ W.float().t() + bias
@@ -80,7 +84,7 @@ def test_gemm_tn_epilogues(K):
     close(g, F.gelu(ref), 4e-3, 1e-3, "gelu.g")
     # bias + residual + per-sample scale (fp32 out)
     resid = rnd(M, N, seed=7)
-    rs = torch.tensor([0.0, 1.0 / 0.9], device="cuda")
+    rs = (torch.arange(M // T, device="cuda") % 2).float() / 0.9
     x = torch.empty(M, N, dtype=torch.float32, device="cuda")
     K.gemm_tn(K.EPI_BIAS_RESID, A, W, x, bias=bias, resid=resid, rowscale=rs, rows_per_sample=T)
     refx = resid + ref * rs.repeat_interleave(T)[:, None]
