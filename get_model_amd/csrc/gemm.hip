@@ -52,13 +52,13 @@ struct GemmArgs {
 // (row = lane&15, 4 consecutive columns per lane).  All global LOADS (bias, residual, pre-activation, row scale)
 // are issued first from clamped addresses -- no predication, one latency exposure per tile instead of one per
 // sub-tile -- then the arithmetic and the predicated stores.
-template <int EPI, int MT, int NT>
-__device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[MT][NT], int em, int en) {
+template <int EPI, int MT, int NT, int MS, int NS, typename Get>
+__device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, int em, int en) {
     float4 bv[NT];
     const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = min(en + nt * 16, p.N - 4);
+        const int n = min(en + nt * NS, p.N - 4);
         bv[nt] = has_bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (EPI == EPI_BIAS_RESID) {
@@ -66,19 +66,19 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[M
         float sc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = min(em + mt * 16, p.M - 1);
+            const int m = min(em + mt * MS, p.M - 1);
             sc[mt] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                rv[mt][nt] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + nt * 16, p.N - 4));
+                rv[mt][nt] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + nt * NS, p.N - 4));
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int m = em + mt * 16, n = en + nt * 16;
+                const int m = em + mt * MS, n = en + nt * NS;
                 if (m < p.M && n < p.N) {
-                    const f32x4 v = acc[mt][nt];
+                    const f32x4 v = acc_get(mt, nt);
                     const float4 r = rv[mt][nt], b = bv[nt];
                     const float s = sc[mt];
                     *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) =
@@ -94,15 +94,15 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[M
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                uv[mt][nt] = *reinterpret_cast<const uint2*>(p.aux + (size_t)min(em + mt * 16, p.M - 1) * p.ldaux +
-                                                             min(en + nt * 16, p.N - 4));
+                uv[mt][nt] = *reinterpret_cast<const uint2*>(p.aux + (size_t)min(em + mt * MS, p.M - 1) * p.ldaux +
+                                                             min(en + nt * NS, p.N - 4));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int m = em + mt * 16, n = en + nt * 16;
+                const int m = em + mt * MS, n = en + nt * NS;
                 if (m < p.M && n < p.N) {
-                    const f32x4 v = acc[mt][nt];
+                    const f32x4 v = acc_get(mt, nt);
                     const uint2 u = uv[mt][nt];
                     *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) =
                         pack4bf(v[0] * dgelu_f(bf2f(u.x & 0xffff)), v[1] * dgelu_f(bf2f(u.x >> 16)),
@@ -115,9 +115,9 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[M
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int m = em + mt * 16, n = en + nt * 16;
+            const int m = em + mt * MS, n = en + nt * NS;
             if (m >= p.M || n >= p.N) continue;
-            f32x4 v = acc[mt][nt];
+            f32x4 v = acc_get(mt, nt);
             v[0] += bv[nt].x; v[1] += bv[nt].y; v[2] += bv[nt].z; v[3] += bv[nt].w;
             if (EPI == EPI_BF16) {
                 *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
@@ -137,6 +137,11 @@ __device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[M
                 *reinterpret_cast<float4*>((float*)p.out0 + orow * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+}
+
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[MT][NT], int em, int en) {
+    epilogue_quads<EPI, MT, NT, 16, 16>(p, [&](int a, int b) -> f32x4 { return acc[a][b]; }, em, en);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,6 +317,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
         glds16(src[J][1] + (size_t)(t) * 128, b_ + dst[J][1]);                                 \
     } while (0)
 
+    // v_mfma_f32_16x16x32_bf16 on purpose: the 32x32x16 form of this same schedule measured ~10 % SLOWER on
+    // random data (the chip holds a higher clock on the 16x16 shape, MI355X_MICROARCH.md DVFS item 7).
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -421,8 +428,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs p) {
 
     const int tiles1 = (p.N1 + 127) / 128, tiles2 = (p.N2 + 127) / 128;
     const int ntile = tiles1 * tiles2;
-    const int split = blockIdx.x / ntile;
-    const int tile = blockIdx.x - split * ntile;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / ntile;
+    const int tile = lid - split * ntile;
     const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
     const int n1_0 = t1 * 128, n2_0 = t2 * 128;
 
@@ -521,6 +529,134 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad, large-tile pipeline: 256(n1) x 256(n2) output tile per workgroup, 64 rows of M per K-tile, same
+// four-phase / half-tile / counted-vmcnt schedule as gemm_tn256_kernel (X plays A, Y plays B).
+// A half-tile is its own [64 m][128 cols] image (256-B rows, v1 swizzle):
+//     X-half h : columns {wr*128 + h*64 + 0..63 | wr = 0,1}  stored at local column wr*64 + c
+//     Y-half h : columns {wc*64  + h*32 + 0..31 | wc = 0..3} stored at local column wc*32 + c
+// LDS: 2 buffers x (X0 | X1 | Y0 | Y1) x 16 KiB = 128 KiB, one workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // XCD-aware order: the tiles of one M-split (same X/Y rows) get consecutive logical ids = one XCD's L2
+    const int tiles2 = p.N2 >> 8;
+    const int ntile = (p.N1 >> 8) * tiles2;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = lid / ntile;
+    const int tile = lid - split * ntile;
+    const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
+    const int n1_0 = t1 << 8, n2_0 = t2 << 8;
+
+    const int nk_total = (p.M + BK - 1) / BK;
+    const int k_begin = split * p.steps_per_split;
+    const int nk = max(0, min(nk_total, k_begin + p.steps_per_split) - k_begin);
+    const int nq = nk << 2;
+
+    // ---- staging: kind j = 0:X-half0 1:Y-half0 2:Y-half1 3:X-half1; 2 wave-instructions (4 rows each) per kind ----
+    int srow[2];
+    int scol[4][2];     // global column of this lane's 16-B chunk
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int row = (wave * 2 + jj) * 4 + (lane >> 4);
+        srow[jj] = row;
+        const int lc = ((lane & 15) ^ wg_swz(row)) * 8;      // local column inside the half image
+        scol[0][jj] = n1_0 + ((lc >> 6) << 7) + (lc & 63);
+        scol[3][jj] = scol[0][jj] + 64;
+        scol[1][jj] = n2_0 + ((lc >> 5) << 6) + (lc & 31);
+        scol[2][jj] = scol[1][jj] + 32;
+    }
+    // LDS offsets of the four half images inside a buffer
+    constexpr int IMG_X0 = 0, IMG_X1 = 16384, IMG_Y0 = 32768, IMG_Y1 = 49152;
+#define W2_ISSUE(t, J)                                                                                        \
+    do {                                                                                                      \
+        char* b_ = smem + (((t)&1) << 16) + ((J) == 0 ? IMG_X0 : (J) == 3 ? IMG_X1 : (J) == 1 ? IMG_Y0 : IMG_Y1); \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                    \
+            const int m_ = (k_begin + (t)) * BK + srow[jj];                                                   \
+            const void* s_;                                                                                   \
+            if ((J) == 0 || (J) == 3) s_ = (m_ < p.M) ? (const void*)(p.X + (size_t)m_ * p.ldx + scol[J][jj]) : (const void*)g_zero_line; \
+            else s_ = (m_ < p.M) ? (const void*)(p.Y + (size_t)m_ * p.ldy + scol[J][jj]) : (const void*)g_zero_line; \
+            glds16(s_, b_ + (wave * 2 + jj) * 1024);                                                          \
+        }                                                                                                     \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed fragment read offsets (bytes inside a half image) for sub-tile 0; sub-tile i: XOR (i << 5)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int xoff[2][2], yoff[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = ks * 32 + 8 * g + 4 * h + q;
+            xoff[ks][h] = m * 256 + tr_col_off(wr * 64 + 4 * pp, m);
+            yoff[ks][h] = m * 256 + tr_col_off(wc * 32 + 4 * pp, m);
+        }
+
+    if (nk > 0) {
+        W2_ISSUE(0, 0); W2_ISSUE(0, 1); W2_ISSUE(0, 2); W2_ISSUE(0, 3);
+        if (nk > 1) { W2_ISSUE(1, 0); W2_ISSUE(1, 1); W2_ISSUE(1, 2); }
+    }
+    bf16x8 fx[4][2], fy0[2][2], fy1[2][2];
+#define W2_LOAD_X(IMG)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)           \
+        fx[i][ks] = join_tr(lds_tr16(buf + (IMG) + (xoff[ks][0] ^ (i << 5))), lds_tr16(buf + (IMG) + (xoff[ks][1] ^ (i << 5))));
+#define W2_LOAD_Y(FY, IMG)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)           \
+        FY[i][ks] = join_tr(lds_tr16(buf + (IMG) + (yoff[ks][0] ^ (i << 5))), lds_tr16(buf + (IMG) + (yoff[ks][1] ^ (i << 5))));
+#define W2_MMA(MH, NH, FY)                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int a = 0; a < 4; ++a)           \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                        \
+            acc[(MH)*4 + a][(NH)*2 + b] =                                                                    \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(FY[b][ks], fx[a][ks], acc[(MH)*4 + a][(NH)*2 + b], 0, 0, 0);
+
+    for (int s = 0; s < nk; ++s) {
+        const char* buf = smem + ((s & 1) << 16);
+        const int phi = s << 2;
+        wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
+        phase_barrier();
+        W2_LOAD_X(IMG_X0)
+        W2_LOAD_Y(fy0, IMG_Y0)
+        if (s + 1 < nk) W2_ISSUE(s + 1, 3);
+        W2_MMA(0, 0, fy0)
+        wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
+        phase_barrier();
+        W2_LOAD_Y(fy1, IMG_Y1)
+        if (s + 2 < nk) W2_ISSUE(s + 2, 0);
+        W2_MMA(0, 1, fy1)
+        wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
+        phase_barrier();
+        W2_LOAD_X(IMG_X1)
+        if (s + 2 < nk) W2_ISSUE(s + 2, 1);
+        W2_MMA(1, 1, fy1)
+        if (s + 2 < nk) W2_ISSUE(s + 2, 2);
+        W2_MMA(1, 0, fy0)
+    }
+#undef W2_ISSUE
+#undef W2_LOAD_X
+#undef W2_LOAD_Y
+#undef W2_MMA
+
+    float* out = p.slabs + (size_t)split * p.N1 * p.N2;
+    const int e1 = n1_0 + wr * 128 + (lane & 15);
+    const int e2 = n2_0 + wc * 64 + (lane >> 4) * 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            *reinterpret_cast<float4*>(out + (size_t)(e1 + a * 16) * p.N2 + e2 + b * 16) =
+                make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]        (n % 4 == 0)
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n,
                                     int nsplit, int accumulate) {
@@ -610,11 +746,22 @@ int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
 }
 
 // choose the number of M-splits so that tiles*splits fills the chip (~2 blocks per CU on 256 CUs)
+static bool wgrad_big(int M, int N1, int N2) {
+    if (g_tile_mode < 0) {
+        const char* e = getenv("GETMI_GEMM_TILE");
+        g_tile_mode = e ? atoi(e) : 0;
+    }
+    if (g_tile_mode == 1) return false;
+    return (N1 % 256 == 0) && (N2 % 256 == 0) && M >= 4096;
+}
+
 int getmi_wgrad_nsplit(int M, int N1, int N2) {
-    const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    const bool big = wgrad_big(M, N1, N2);
+    const int ntile = big ? (N1 / 256) * (N2 / 256) : ((N1 + 127) / 128) * ((N2 + 127) / 128);
     const int nk = (M + BK - 1) / BK;
-    // one full wave of blocks at 2 blocks/CU (512 slots): never spill a few blocks into a second round
-    int want = 512 / ntile;
+    // one full wave of blocks (big tile: 1 block/CU -> 256 slots; 128x128: 2 blocks/CU -> 512 slots): never
+    // spill a few blocks into a second round
+    int want = (big ? 256 : 512) / ntile;
     if (want < 1) want = 1;
     if (want > nk) want = nk;
     if (want > 64) want = 64;
@@ -643,8 +790,18 @@ int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N
     a.X = X; a.Y = Y; a.M = M; a.N1 = N1; a.N2 = N2; a.ldx = ldx; a.ldy = ldy; a.slabs = slabs;
     const int nk = (M + BK - 1) / BK;
     a.steps_per_split = (nk + nsplit - 1) / nsplit;
-    const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
-    hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(ntile * nsplit), dim3(256), GEMM_LDS, st, a);
+    if (wgrad_big(M, N1, N2)) {
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad256_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL(gemm_wgrad256_kernel, dim3((N1 / 256) * (N2 / 256) * nsplit), dim3(512), G2_LDS, st, a);
+    } else {
+        const int ntile = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+        hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(ntile * nsplit), dim3(256), GEMM_LDS, st, a);
+    }
     GETMI_CHECK_LAUNCH("gemm_wgrad");
     const size_t n = (size_t)N1 * N2;
     int rgrid = (int)((n / 4 + 255) / 256);

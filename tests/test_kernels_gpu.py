@@ -120,7 +120,10 @@ def test_gemm_tn_embed(K):
 
 
 @pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (201, 768, 768), (1005, 768, 2304), (804, 3072, 768),
-                                     (130, 768, 320), (4000, 288, 768)])
+                                     (130, 768, 320), (4000, 288, 768),
+                                     # M >= 4096 with N1, N2 multiples of 256: the 256x256 deep-pipelined kernel
+                                     (4096, 256, 256), (4100, 768, 768), (5001, 256, 512), (8200, 768, 2304),
+                                     (12345, 3072, 768)])
 def test_gemm_wgrad_asymmetric(K, M, N1, N2):
     X = ((torch.arange(M * N1).reshape(M, N1) * 7 + 3) % 5 - 2).float().cuda()
     Y = ((torch.arange(M * N2).reshape(M, N2) * 3 + 1) % 7 - 3).float().cuda()
