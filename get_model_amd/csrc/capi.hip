@@ -5,8 +5,11 @@
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; int M, N, K, lda, ldb; void* out0; void* out1; int ldo; const float* bias;
     const float* resid; const float* rowscale; int rows_per_sample; const bf16_t* aux; int ldaux;
-    const uint8_t* mask; const float* mask_token; int regions_per_sample;
+    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum;
 };
+int getmi_gemm_tn_colsum_rows(int M, int N);
+int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
+                         hipStream_t st);
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st);
 int getmi_wgrad_nsplit(int M, int N1, int N2);
 int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N2, int ldx, int ldy, float* out,
@@ -56,13 +59,23 @@ int getmi_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, voi
 int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, void* stream) {
     return getmi_qkv_bias_impl(q_bias, v_bias, out, D, ST(stream));
 }
+size_t getmi_gemm_tn_workspace_bytes(int M, int N) { return (size_t)getmi_gemm_tn_colsum_rows(M, N) * N * sizeof(float); }
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0, void* out1,
                   int ldo, const float* bias, const float* resid, const float* rowscale, int rows_per_sample,
                   const void* aux, int ldaux, const uint8_t* mask, const float* mask_token, int regions_per_sample,
-                  void* stream) {
+                  float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
-               mask, mask_token, regions_per_sample};
-    return getmi_gemm_tn_impl(epi, a, ST(stream));
+               mask, mask_token, regions_per_sample, nullptr};
+    if (dbias) {
+        GETMI_CHECK_ARG(epi == 3, "gemm_tn: dbias (fused column sums) is only produced by the DGELU epilogue");
+        GETMI_CHECK_ARG(workspace && workspace_bytes >= getmi_gemm_tn_workspace_bytes(M, N) &&
+                            ((uintptr_t)workspace % 16 == 0),
+                        "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");
+        a.colsum = reinterpret_cast<float*>(workspace);
+    }
+    if (int rc = getmi_gemm_tn_impl(epi, a, ST(stream))) return rc;
+    if (dbias) return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, getmi_gemm_tn_colsum_rows(M, N), N, 0, ST(stream));
+    return 0;
 }
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2) {
     return (size_t)getmi_wgrad_nsplit(M, N1, N2) * N1 * N2 * sizeof(float);

@@ -40,6 +40,7 @@ struct GemmArgs {
     const uint8_t* mask;
     const float* mask_token;
     int regions_per_sample;
+    float* colsum;   // EPI_DGELU only: partial column sums of out0 (fp32, pre-rounding) [rows][N]; may be null
 };
 
 #define BM 128
@@ -53,7 +54,7 @@ struct GemmArgs {
 // are issued first from clamped addresses -- no predication, one latency exposure per tile instead of one per
 // sub-tile -- then the arithmetic and the predicated stores.
 template <int EPI, int MT, int NT, int MS, int NS, typename Get>
-__device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, int em, int en) {
+__device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, int em, int en, int prow = 0) {
     float4 bv[NT];
     const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;
 #pragma unroll
@@ -90,6 +91,9 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
     }
     if (EPI == EPI_DGELU) {
         uint2 uv[MT][NT];
+        float4 cs[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) cs[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -104,11 +108,28 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 if (m < p.M && n < p.N) {
                     const f32x4 v = acc_get(mt, nt);
                     const uint2 u = uv[mt][nt];
-                    *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) =
-                        pack4bf(v[0] * dgelu_f(bf2f(u.x & 0xffff)), v[1] * dgelu_f(bf2f(u.x >> 16)),
-                                v[2] * dgelu_f(bf2f(u.y & 0xffff)), v[3] * dgelu_f(bf2f(u.y >> 16)));
+                    const float d0 = v[0] * dgelu_f(bf2f(u.x & 0xffff)), d1 = v[1] * dgelu_f(bf2f(u.x >> 16));
+                    const float d2 = v[2] * dgelu_f(bf2f(u.y & 0xffff)), d3 = v[3] * dgelu_f(bf2f(u.y >> 16));
+                    *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(d0, d1, d2, d3);
+                    cs[nt].x += d0; cs[nt].y += d1; cs[nt].z += d2; cs[nt].w += d3;
                 }
             }
+        if (p.colsum) {
+            // bias gradient of the previous Linear = column sums of this output: reduce the wave's rows
+            // (in-lane over mt, then over the 16 lanes that share a column group) and write one partial row.
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float4 c = cs[nt];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    c.x += __shfl_xor(c.x, o, 64); c.y += __shfl_xor(c.y, o, 64);
+                    c.z += __shfl_xor(c.z, o, 64); c.w += __shfl_xor(c.w, o, 64);
+                }
+                const int n = en + nt * NS;
+                if ((threadIdx.x & 15) == 0 && n < p.N)
+                    *reinterpret_cast<float4*>(p.colsum + (size_t)prow * p.N + n) = c;
+            }
+        }
         return;
     }
 #pragma unroll
@@ -140,8 +161,8 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
 }
 
 template <int EPI, int MT, int NT>
-__device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[MT][NT], int em, int en) {
-    epilogue_quads<EPI, MT, NT, 16, 16>(p, [&](int a, int b) -> f32x4 { return acc[a][b]; }, em, en);
+__device__ __forceinline__ void epilogue_tiles(const GemmArgs& p, f32x4 (&acc)[MT][NT], int em, int en, int prow = 0) {
+    epilogue_quads<EPI, MT, NT, 16, 16>(p, [&](int a, int b) -> f32x4 { return acc[a][b]; }, em, en, prow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs p) {
 
     const int em = m0 + wr * 64 + (lane & 15);
     const int en = n0 + wc * 64 + (lane >> 4) * 4;
-    epilogue_tiles<EPI, 4, 4>(p, acc, em, en);
+    epilogue_tiles<EPI, 4, 4>(p, acc, em, en, tm * 2 + wr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,8 +405,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
 
     const int em = m0 + wm * 128 + (lane & 15);
     const int en = n0 + wn * 64 + (lane >> 4) * 4;
-    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), em, en);
-    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), em + 64, en);
+    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), em, en, tm * 4 + wm * 2);
+    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), em + 64, en, tm * 4 + wm * 2 + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -713,6 +734,13 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(grid), dim3(256), GEMM_LDS, st, a);
     GETMI_CHECK_LAUNCH("gemm_tn");
     return GETMI_OK;
+}
+
+// number of partial rows the DGELU column-sum epilogue writes for this problem (depends on the tile choice)
+int getmi_gemm_tn_colsum_rows(int M, int N) {
+    GemmArgs a{};
+    a.M = M; a.N = N;
+    return use_big_tile(a) ? ((M + 255) / 256) * 4 : ((M + 127) / 128) * 2;
 }
 
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {

@@ -168,12 +168,12 @@ class EncoderBlock(torch.autograd.Function):
         # ---- MLP branch ----
         dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
         du = torch.empty_like(u)
-        K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u)               # (dz2 @ W2) * gelu'(u)
+        dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
+        K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)  # (dz2 @ W2) * gelu'(u), + column sums
         dfc2_w = K.gemm_wgrad(dz2, g) if need[12] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
         dfc1_w = K.gemm_wgrad(du, h2) if need[10] else None
-        dfc1_b = K.colsum_bf16(du) if need[11] else None
         dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
                                                            want_dbias=True)
@@ -186,9 +186,10 @@ class EncoderBlock(torch.autograd.Function):
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
         dqkv_w = K.gemm_wgrad(dqkv, h1) if need[3] else None
         dq_bias = dv_bias = None
-        if need[4] or need[5]:
-            dqb = K.colsum_bf16(dqkv)
-            dq_bias, dv_bias = dqb[:D], dqb[2 * D:]
+        if need[4]:
+            dq_bias = K.colsum_bf16(dqkv[:, :D])          # the K third has no bias (model/transformer.py:53)
+        if need[5]:
+            dv_bias = K.colsum_bf16(dqkv[:, 2 * D:])
         dx_in, _, dn1w, dn1b, _ = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid)
         return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
                 dfc1_b, dfc2_w, dfc2_b, None, None, None, None)

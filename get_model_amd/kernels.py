@@ -80,17 +80,18 @@ def qkv_bias(q_bias, v_bias):
 
 
 def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, rows_per_sample=0, aux=None,
-            mask=None, mask_token=None, regions_per_sample=0, M=None):
+            mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None):
     """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated."""
     _chk(A, B, out0, out1, bias, resid, rowscale, aux, mask, mask_token)
     M = A.shape[0] if M is None else M
     K = A.shape[1]
     N = B.shape[0]
     assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
+    ws = None if dbias is None else _ws(lib.query("getmi_gemm_tn_workspace_bytes", M, N), A.device)
     e0 = _prof_begin()
     lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, out0.shape[-1], bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
-             regions_per_sample)
+             regions_per_sample, dbias, ws, 0 if ws is None else ws.numel())
     _prof_end(e0, "gemm_tn_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K)
     return out0
 
@@ -249,7 +250,9 @@ def gather_rows(src, idx, n_out=None, scatter=False):
 
 
 def colsum_bf16(X, M=None):
-    _chk(X)
+    """Column sums of a bf16 matrix (row stride may exceed the column count: column slices are fine)."""
+    if not (X.is_cuda and X.stride(1) == 1):
+        raise RuntimeError("getmi355 kernels need GPU tensors with unit column stride")
     M = X.shape[0] if M is None else M
     N = X.shape[1]
     out = torch.empty(N, dtype=F32, device=X.device)

@@ -21,7 +21,9 @@ _SIGNATURES = {
     "getmi_cast_pad_f32_bf16": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "getmi_cast_transpose_f32_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "getmi_qkv_bias": (_i, [_vp, _vp, _vp, _i, _vp]),
-    "getmi_gemm_tn": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "getmi_gemm_tn": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp,
+                           _sz, _vp]),
+    "getmi_gemm_tn_workspace_bytes": (_sz, [_i, _i]),
     "getmi_gemm_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "getmi_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

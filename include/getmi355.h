@@ -51,7 +51,10 @@ int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, 
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0,
                   void* out1, int ldo, const float* bias, const float* resid, const float* rowscale,
                   int rows_per_sample, const void* aux, int ldaux, const uint8_t* mask, const float* mask_token,
-                  int regions_per_sample, void* stream);
+                  int regions_per_sample, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* DGELU only: dbias[N] (optional) = column sums of out0 before rounding = bias gradient of the Linear whose
+ * pre-activation is `aux` (fc1.bias); needs workspace of getmi_gemm_tn_workspace_bytes(M, N). */
+size_t getmi_gemm_tn_workspace_bytes(int M, int N);
 /* out[N1,N2] (+)= X[M,N1]^T * Y[M,N2]  (weight gradient; autograd of F.linear).  bf16 operands, fp32 out. */
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2);
 int getmi_gemm_wgrad(const void* X, const void* Y, int M, int N1, int N2, int ldx, int ldy, float* out,

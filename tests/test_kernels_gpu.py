@@ -94,10 +94,13 @@ def test_gemm_tn_epilogues(K, M):
     # dgelu
     pre = bf(rnd(M, N, seed=8))
     d = torch.empty_like(o)
-    K.gemm_tn(K.EPI_DGELU, A, W, d, aux=pre)
+    dbias = torch.empty(N, device="cuda")
+    K.gemm_tn(K.EPI_DGELU, A, W, d, aux=pre, dbias=dbias)
     xp = pre.float().requires_grad_(True)
     F.gelu(xp).sum().backward()
-    close(d, (A.float() @ W.float().t()) * xp.grad, 4e-3, 2e-3, "dgelu")
+    refd = (A.float() @ W.float().t()) * xp.grad
+    close(d, refd, 4e-3, 2e-3, "dgelu")
+    close(dbias, refd.sum(0), 1e-3, 2e-3 * math.sqrt(M), "dgelu.colsum")
 
 
 def test_gemm_tn_embed(K):
