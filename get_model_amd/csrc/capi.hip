@@ -72,6 +72,11 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
                             ((uintptr_t)workspace % 16 == 0),
                         "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");
         a.colsum = reinterpret_cast<float*>(workspace);
+        // kernels write one partial row per (tile, wave-row[, half]); rows a variant does not use must read as zero
+        if (hipMemsetAsync(workspace, 0, getmi_gemm_tn_workspace_bytes(M, N), ST(stream)) != hipSuccess) {
+            getmi_set_error("gemm_tn: workspace memset failed");
+            return GETMI_ERR_LAUNCH;
+        }
     }
     if (int rc = getmi_gemm_tn_impl(epi, a, ST(stream))) return rc;
     if (dbias) return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, getmi_gemm_tn_colsum_rows(M, N), N, 0, ST(stream));

@@ -410,6 +410,398 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_tn, PERSISTENT form of the 256x256 pipeline: one workgroup per CU walks its output tiles
+// (tile = iteration*grid + xcd_remap(block)), and the half-tile stream simply continues from the last K-tile of
+// one output tile into the first K-tiles of the next (the LDS ring never drains).  Two things are overlapped that
+// the one-tile-per-workgroup form serialises, both visible in rocprof as the gap between its in-loop rate
+// (~1.3 PF) and its end-to-end rate on output-heavy shapes (0.6 PF for fc1):
+//   * the next tile's operand prefetch runs under the current tile's last phases and its epilogue;
+//   * the epilogue's global STORES (HBM-bound: every CU used to write at the same time, then all computed) drain
+//     under the next tile's MFMAs.
+// vmcnt is one in-order counter for loads, LDS-DMA and stores, so a counted wait for a half-tile issued BEFORE an
+// epilogue must also allow that epilogue's stores to stay outstanding: for the five reading phases whose needed
+// half-tile predates the last epilogue the wait is vmcnt(10 + E) with E = the EXACT number of store instructions
+// every wave executes in the epilogue.  Exactness is why the stores are inline-asm buffer stores (never merged,
+// split or skipped; out-of-range lanes are dropped by the buffer bounds check instead of by a branch).
+// Under-counting E would only wait longer; over-counting would read LDS before the data landed.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#define OOB_OFF 0xFFFFFFF0u
+
+__device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    return (u32x4){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void st_b64(u32x2 v, unsigned off, u32x4 rs) {
+    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ void st_b128(u32x4 v, unsigned off, u32x4 rs) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+}
+__device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
+    return (u32x2){pack2bf(a, b), pack2bf(c, d)};
+}
+
+template <int EPI>
+struct EpiStores {   // buffer-store instructions per wave and output tile (lower bound used in the counted waits)
+    static constexpr int value = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) ? 32 : 16;
+};
+
+// wait until at most 2*halftiles (+ EXTRA) vector-memory operations of this wave are outstanding
+template <int EXTRA>
+__device__ __forceinline__ void wait_halftiles_x(int halftiles) {
+    constexpr int C5 = (10 + EXTRA > 63) ? 63 : 10 + EXTRA, C4 = (8 + EXTRA > 63) ? 63 : 8 + EXTRA,
+                  C3 = (6 + EXTRA > 63) ? 63 : 6 + EXTRA, C2 = (4 + EXTRA > 63) ? 63 : 4 + EXTRA,
+                  C1 = (2 + EXTRA > 63) ? 63 : 2 + EXTRA, C0 = (EXTRA > 63) ? 63 : EXTRA;
+    if (halftiles >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C5) : "memory");
+    else if (halftiles == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C4) : "memory");
+    else if (halftiles == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C3) : "memory");
+    else if (halftiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C2) : "memory");
+    else if (halftiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C0) : "memory");
+}
+
+// Wave-private LDS transposition of one 16-row x 128-byte block, entirely in inline asm: a compiler-visible access
+// to LDS that LDS-DMA also writes makes hipcc drain vmcnt to 0 first.  Writes, wait, reads, wait in ONE statement
+// (outputs early-clobber), so no register is reused before the LDS has consumed / produced it.
+__device__ __forceinline__ void stage_w64x4_r128x2(unsigned wa, unsigned ra, u32x2 q0, u32x2 q1, u32x2 q2, u32x2 q3,
+                                                   u32x4& d0, u32x4& d1) {
+    asm volatile(
+        "ds_write_b64 %2, %6\n\tds_write_b64 %3, %7\n\tds_write_b64 %4, %8\n\tds_write_b64 %5, %9\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(d0), "=&v"(d1)
+        : "v"(wa), "v"(wa ^ 32u), "v"(wa ^ 64u), "v"(wa ^ 96u), "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(ra)
+        : "memory");
+}
+__device__ __forceinline__ void stage_w128x2_r128x2(unsigned wa, unsigned ra, u32x4 q0, u32x4 q1, u32x4& d0, u32x4& d1) {
+    asm volatile(
+        "ds_write_b128 %2, %4\n\tds_write_b128 %3, %5\n\ts_waitcnt lgkmcnt(0)\n\t"
+        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(d0), "=&v"(d1)
+        : "v"(wa), "v"(wa ^ 64u), "v"(q0), "v"(q1), "v"(ra)
+        : "memory");
+}
+
+// Epilogue of one wave's 128 x 64 output block (acc[a][b]: rows 16a + (lane&15), columns 16b + 4*(lane>>4) .. +3).
+// Stores are re-shaped through a 2-KiB wave-private LDS stage so that every global store instruction writes whole
+// 128-byte lines (16 B per lane, 8 rows x 128 B per instruction): the accumulator layout itself gives 8-byte
+// pieces on 16 different rows per instruction, which measured store-ISSUE bound (the epilogue ran no faster when
+// it was overlapped with the next tile's MFMAs).  XOR swizzle of the 16-B chunk with (row & 7) keeps the LDS
+// writes at most 2-way conflicted.  m0w / n0w: first row / column of the wave's block.
+template <int EPI>
+__device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4], int m0w, int n0w, int prow,
+                                           u32x4 rs0, u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, c = lane >> 4;
+    const int rrow = lane >> 3, rch = lane & 7;          // read-back: 8 rows x 8 chunks per pass
+    float4 bv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != EPI_DGELU && bias_lds != nullptr) {
+        // inline asm on purpose: a compiler-visible ds_read of LDS-DMA-written memory makes hipcc emit
+        // s_waitcnt vmcnt(0) (draining the operand prefetch and the previous tile's stores).  The bias DMA is
+        // known complete here: it was issued >= 12 vector-memory operations before the last counted wait.
+        f32x4 b0, b1, b2, b3;
+        const unsigned addr = (unsigned)(unsigned long)((__attribute__((address_space(3))) const float*)bias_lds);
+        asm volatile(
+            "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+            "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+            : "v"(addr)
+            : "memory");
+        bv[0] = make_float4(b0[0], b0[1], b0[2], b0[3]);
+        bv[1] = make_float4(b1[0], b1[1], b1[2], b1[3]);
+        bv[2] = make_float4(b2[0], b2[1], b2[2], b2[3]);
+        bv[3] = make_float4(b3[0], b3[1], b3[2], b3[3]);
+    }
+    // LDS stage addressing (LDS byte addresses): 16 rows x 128 B, 16-B chunk index XOR (row & 7)
+    const unsigned sbase = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)stage);
+    const unsigned ra = sbase + rrow * 128 + ((rch ^ (rrow & 7)) << 4);     // + 1024 for rows 8..15 (same row & 7)
+    const int em = m0w + r, en = n0w + c * 4;
+
+    if (EPI == EPI_BIAS_RESID) {
+        // fp32 output: a row block of 16 rows x 32 columns (128 B per row) per stage pass
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 rv[4][4];
+            float sc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = min(em + (half * 4 + a) * 16, p.M - 1);
+                sc[a] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    rv[a][b] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + b * 16, p.N - 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp) {
+                    u32x4 qv[2], dd[2];
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int b = bp * 2 + bb;
+                        const f32x4 v = acc[half * 4 + a][b];
+                        const float4 q = rv[a][b], bi = bv[b];
+                        const float s_ = sc[a];
+                        const f32x4 o = {q.x + s_ * (v[0] + bi.x), q.y + s_ * (v[1] + bi.y), q.z + s_ * (v[2] + bi.z),
+                                         q.w + s_ * (v[3] + bi.w)};
+                        qv[bb] = __builtin_bit_cast(u32x4, o);
+                    }
+                    // 16-B chunk index of (bb, c) is bb*4 + c
+                    stage_w128x2_r128x2(sbase + r * 128 + ((c ^ (r & 7)) << 4), ra, qv[0], qv[1], dd[0], dd[1]);
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int row = ps * 8 + rrow;
+                        const int m = m0w + (half * 4 + a) * 16 + row, n = n0w + bp * 32 + rch * 4;
+                        const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 4) : OOB_OFF;
+                        st_b128(dd[ps], off, rs0);
+                    }
+                }
+        }
+        return;
+    }
+
+    float4 cs[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cs[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint2 uv[4][4];
+        if (EPI == EPI_DGELU) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    uv[a][b] = *reinterpret_cast<const uint2*>(p.aux + (size_t)min(em + (half * 4 + a) * 16, p.M - 1) * p.ldaux +
+                                                               min(en + b * 16, p.N - 4));
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ab = half * 4 + a;
+            const bool mok = (em + ab * 16) < p.M;
+            // bf16 output(s): 16 rows x 64 columns (128 B per row) per stage pass
+#pragma unroll
+            for (int outp = 0; outp < (EPI == EPI_BIAS_GELU ? 2 : 1); ++outp) {
+                u32x2 qv[4];
+                u32x4 dd[2];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    f32x4 v = acc[ab][b];
+                    float d0, d1, d2, d3;
+                    if (EPI == EPI_DGELU) {
+                        const uint2 u = uv[a][b];
+                        d0 = v[0] * dgelu_f(bf2f(u.x & 0xffff)); d1 = v[1] * dgelu_f(bf2f(u.x >> 16));
+                        d2 = v[2] * dgelu_f(bf2f(u.y & 0xffff)); d3 = v[3] * dgelu_f(bf2f(u.y >> 16));
+                        if (mok && (en + b * 16) < p.N) { cs[b].x += d0; cs[b].y += d1; cs[b].z += d2; cs[b].w += d3; }
+                    } else {
+                        d0 = v[0] + bv[b].x; d1 = v[1] + bv[b].y; d2 = v[2] + bv[b].z; d3 = v[3] + bv[b].w;
+                        if (outp == 1) { d0 = gelu_f(d0); d1 = gelu_f(d1); d2 = gelu_f(d2); d3 = gelu_f(d3); }
+                    }
+                    qv[b] = pack4bf_v(d0, d1, d2, d3);
+                }
+                // 8-byte piece of (b, c): columns b*16 + c*4 .. +3 -> 16-B chunk (b*2 + (c>>1)), half (c&1)
+                stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qv[0], qv[1], qv[2],
+                                   qv[3], dd[0], dd[1]);
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int row = ps * 8 + rrow;
+                    const int m = m0w + ab * 16 + row, n = n0w + rch * 8;
+                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 2) : OOB_OFF;
+                    st_b128(dd[ps], off, outp == 0 ? rs0 : rs1);
+                }
+            }
+        }
+    }
+    if (EPI == EPI_DGELU && p.colsum) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float4 cc = cs[b];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                cc.x += __shfl_xor(cc.x, o, 64); cc.y += __shfl_xor(cc.y, o, 64);
+                cc.z += __shfl_xor(cc.z, o, 64); cc.w += __shfl_xor(cc.w, o, 64);
+            }
+            const int n = en + b * 16;
+            const unsigned off = (r == 0 && n < p.N) ? (unsigned)(((size_t)prow * p.N + n) * 4) : OOB_OFF;
+            const f32x4 cv = {cc.x, cc.y, cc.z, cc.w};
+            st_b128(__builtin_bit_cast(u32x4, cv), off, rsc);
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = EpiStores<EPI>::value;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int G = gridDim.x;
+    const int bslot = xcd_remap(blockIdx.x, G);
+    const int tiles_n = (p.N + 255) >> 8;
+    const int nk = p.K >> 6;                                    // >= 2 (host-checked)
+    const int ntl = (ntiles - bslot + G - 1) / G;               // tiles of this workgroup (>= 1: G <= ntiles)
+    const int Gk = ntl * nk;                                    // K-tiles of this workgroup's stream
+    const int Q = Gk << 2;                                      // half-tiles of the stream
+
+    const unsigned esz = (EPI == EPI_BIAS_RESID) ? 4u : 2u;
+    const u32x4 rs0 = make_rsrc(p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
+    const u32x4 rs1 = make_rsrc(p.out1 ? p.out1 : p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
+    const u32x4 rsc = make_rsrc(p.colsum ? (const void*)p.colsum : (const void*)p.out0,
+                                p.colsum ? (unsigned)((size_t)((p.M + 255) / 256) * 4 * p.N * 4) : 0u);
+
+    // ---- staging offsets (bytes from p.A / p.B) of the current and the next output tile ----
+    unsigned cur[4][2], nxt[4][2];
+    int dst[4][2];
+    auto tile_offsets = [&](int it, unsigned (&o)[4][2]) {
+        const int lid = min(it * G + bslot, ntiles - 1);
+        const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int hr = (wave * 2 + jj) * 8 + (lane >> 3);
+                if (j == 0 || j == 3) {
+                    const int row = ((hr >> 6) << 7) + (j == 3) * 64 + (hr & 63);
+                    const int g = min((tm << 8) + row, p.M - 1);
+                    o[j][jj] = (unsigned)((size_t)g * p.lda * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                } else {
+                    const int row = ((hr >> 5) << 6) + (j - 1) * 32 + (hr & 31);
+                    const int g = min((tn << 8) + row, p.N - 1);
+                    o[j][jj] = (unsigned)((size_t)g * p.ldb * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                }
+            }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int hr0 = (wave * 2 + jj) * 8;
+            if (j == 0 || j == 3) dst[j][jj] = (((hr0 >> 6) << 7) + (j == 3) * 64 + (hr0 & 63)) * 128;
+            else dst[j][jj] = 32768 + (((hr0 >> 5) << 6) + (j - 1) * 32 + (hr0 & 31)) * 128;
+        }
+    tile_offsets(0, cur);
+    tile_offsets(1, nxt);
+    int tile_g0 = 0;            // stream index of the current tile's first K-tile
+    int it = 0;                 // tile iteration of this workgroup
+
+    const char* baseA = reinterpret_cast<const char*>(p.A);
+    const char* baseB = reinterpret_cast<const char*>(p.B);
+    // issue half-tile J of stream K-tile gi (gi is in the current or in the next output tile)
+#define GP_ISSUE(gi, J)                                                                                    \
+    do {                                                                                                   \
+        const int gi_ = (gi);                                                                              \
+        const bool nx_ = gi_ >= tile_g0 + nk;                                                              \
+        const unsigned koff_ = (unsigned)(gi_ - tile_g0 - (nx_ ? nk : 0)) * 128u;                          \
+        char* b_ = smem + ((gi_ & 1) << 16);                                                               \
+        const char* base_ = ((J) == 0 || (J) == 3) ? baseA : baseB;                                        \
+        glds16(base_ + (size_t)((nx_ ? nxt[J][0] : cur[J][0]) + koff_), b_ + dst[J][0]);                    \
+        glds16(base_ + (size_t)((nx_ ? nxt[J][1] : cur[J][1]) + koff_), b_ + dst[J][1]);                    \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * 128 + (((4 * ks + (lane >> 4)) ^ fsw) << 4);
+    const int a_base = (wm * 128) * 128;
+    const int b_base = 32768 + (wn * 64) * 128;
+
+    // per-wave LDS copy of the current tile's bias row segment [n0, n0+256): one 1-KiB LDS-DMA per wave and tile
+    const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;      // workgroup-uniform
+    char* bias_img = smem + G2_LDS;                      // 1 KiB shared image: every wave DMA-writes the same values
+    char* stage = smem + G2_LDS + 1024 + wave * 2048;    // 2 KiB wave-private store stage
+    auto stage_bias = [&](int iter) {
+        const int lid = min(iter * G + bslot, ntiles - 1);
+        const int tn = lid % tiles_n;
+        glds16(p.bias + min((tn << 8) + lane * 4, p.N - 4), bias_img);
+    };
+    if (has_bias) stage_bias(0);
+    GP_ISSUE(0, 0); GP_ISSUE(0, 1); GP_ISSUE(0, 2); GP_ISSUE(0, 3);
+    GP_ISSUE(1, 0); GP_ISSUE(1, 1); GP_ISSUE(1, 2);              // Gk >= 2
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define GP_LOAD_A(MH)                                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        fa[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + ((MH)*64 + mt * 16) * 128 + foff[ks]);
+#define GP_LOAD_B(FB, NH)                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
+        FB[nt][ks] = *reinterpret_cast<const bf16x8*>(buf + b_base + ((NH)*32 + nt * 16) * 128 + foff[ks]);
+#define GP_MMA(MH, NH, FB)                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
+            acc[(MH)*4 + mt][(NH)*2 + nt] =                                                                \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt][ks], fa[mt][ks], acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
+    // counted wait of a reading phase: `win` > 0 while the needed half-tile predates the last epilogue
+#define GP_WAIT(inflight)                                                                                  \
+    do {                                                                                                   \
+        if (win > 0) { wait_halftiles_x<E>(inflight); --win; }                                             \
+        else wait_halftiles_x<0>(inflight);                                                                \
+    } while (0)
+
+    int win = 0;
+    for (int g = 0; g < Gk; ++g) {
+        const char* buf = smem + ((g & 1) << 16);
+        const int phi = g << 2;
+        // ---- P1 ----
+        GP_WAIT(min(phi + 6, Q - 1) - (phi + 1));
+        phase_barrier();
+        GP_LOAD_A(0)
+        GP_LOAD_B(fb0, 0)
+        if (g + 1 < Gk) GP_ISSUE(g + 1, 3);
+        GP_MMA(0, 0, fb0)
+        // ---- P2 ----
+        GP_WAIT(min(phi + 7, Q - 1) - (phi + 2));
+        phase_barrier();
+        GP_LOAD_B(fb1, 1)
+        if (g + 2 < Gk) GP_ISSUE(g + 2, 0);
+        GP_MMA(0, 1, fb1)
+        // ---- P3 ----
+        GP_WAIT(min(phi + 8, Q - 1) - (phi + 3));
+        phase_barrier();
+        GP_LOAD_A(1)
+        if (g + 2 < Gk) GP_ISSUE(g + 2, 1);
+        GP_MMA(1, 1, fb1)
+        // ---- P4 ----
+        if (g + 2 < Gk) GP_ISSUE(g + 2, 2);
+        GP_MMA(1, 0, fb0)
+
+        if (g - tile_g0 == nk - 1) {
+            // ---- tile finished: epilogue (its stores drain under the next tile), then switch tiles ----
+            const int lid = it * G + bslot;
+            const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+            const float* bl = has_bias ? reinterpret_cast<const float*>(bias_img) + wn * 64 + (lane >> 4) * 4 : nullptr;
+            epilogue_p<EPI>(p, acc, (tm << 8) + wm * 128, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ++it;
+            tile_g0 += nk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+            tile_offsets(it + 1, nxt);
+            if (has_bias && it < ntl) stage_bias(it);     // after the epilogue's LDS reads (same wave, in order)
+            win = 5;
+        }
+    }
+#undef GP_ISSUE
+#undef GP_LOAD_A
+#undef GP_LOAD_B
+#undef GP_MMA
+#undef GP_WAIT
+}
+
+// ------------------------------------------------------------------------------------------------
 // C[N1,N2] (+)= X[M,N1]^T * Y[M,N2]   (wgrad), split over M: block (tile, s) handles K-steps
 // [s*steps_per_split, ...) and writes the fp32 slab s.
 // LDS image of one operand tile: [64 rows(m)][16 chunks of 16 B] (256-B rows); chunk index XORed with
@@ -721,9 +1113,43 @@ static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
     return GETMI_OK;
 }
 
+static int g_num_cu = 0;
+template <int EPI>
+static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256p_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS + 1024 + 16384);
+        attr_set = true;
+    }
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_num_cu = n;
+    }
+    const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const int grid = ntiles < g_num_cu ? ntiles : g_num_cu;
+    hipLaunchKernelGGL(gemm_tn256p_kernel<EPI>, dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles);
+    GETMI_CHECK_LAUNCH("gemm_tn256p");
+    return GETMI_OK;
+}
+
 template <int EPI>
 static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
-    if (use_big_tile(a)) return launch_gemm_tn256<EPI>(a, st);
+    if (use_big_tile(a)) {
+        // BIAS_RESID stays on the one-tile-per-workgroup kernel: its epilogue LOADS the fp32 residual (ordinary loads
+        // force a vmcnt(0) drain) and measured 302 vs 278 us (fc2) persistent vs not.
+        constexpr bool can_persist = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_DGELU);
+        const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
+        const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
+                            (size_t)a.M * a.ldo * esz < 0xF0000000ull;
+        if constexpr (can_persist) {
+            if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3) return launch_gemm_tn256p<EPI>(a, st);
+        }
+        return launch_gemm_tn256<EPI>(a, st);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<EPI>),
