@@ -124,26 +124,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
                             kb + row * 128 + (((2 * kk + h2) ^ swz128(row)) << 4));
                         s = MFMA32(kf, qf[kk], s);
                     }
-                    float mloc = -INFINITY;
+                    // (this loop is VALU-issue bound, not MFMA bound: keep the per-element work at max / fma / exp / add)
+                    if (key0 + 32 > T) {   // only the last sub-block has padded keys (wave-uniform)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-                        s[i] = (key < T) ? s[i] * c2 : -INFINITY;
-                        mloc = fmaxf(mloc, s[i]);
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                            s[i] = (key < T) ? s[i] : -INFINITY;
+                        }
                     }
-                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                    float mloc = s[0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s[i]);
+                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64)) * c2;       // c2 > 0: max commutes with the scale
                     const float mnew = fmaxf(m, mloc);
-                    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
                     float lsum = 0.f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        s[i] = __builtin_amdgcn_exp2f(s[i] - mnew);
+                        s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -mnew));
                         lsum += s[i];
                     }
-                    l = l * alpha + lsum;
-                    m = mnew;
+                    if (__builtin_amdgcn_ballot_w64(mnew != m) != 0) {   // running max grew somewhere: rescale (exact)
+                        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                        l *= alpha;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                        m = mnew;
+                    }
+                    l += lsum;
                     bf16x8 pf[2];
                     pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
                     pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);

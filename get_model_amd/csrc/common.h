@@ -74,6 +74,45 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return fmaf(x, pdf, Phi);
 }
 
+// ---- transposed LDS reads (ds_read_b64_tr_b16) in inline asm ------------------------------------------------
+// hipcc emits `s_waitcnt vmcnt(0)` in front of the __builtin_amdgcn_ds_read_tr16_b64 intrinsic whenever an
+// LDS-DMA (global_load_lds) is in flight -- it cannot prove the read does not alias the DMA target -- which
+// drains the whole operand prefetch every phase (measured: wgrad waves 50 % in s_waitcnt).  The asm form is
+// invisible to that pass; ordering against the DMA is done by the kernels' own counted vmcnt + barrier.
+// Eight reads (= four 8-element MFMA fragments) and their lgkmcnt wait in ONE statement, early-clobber outputs.
+typedef __attribute__((ext_vector_type(2))) unsigned tr64_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ bf16x8 join_tr64(tr64_t lo, tr64_t hi) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4_t;
+    const u4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void tr_read8(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5,
+                                         unsigned a6, unsigned a7, bf16x8& f0, bf16x8& f1, bf16x8& f2, bf16x8& f3) {
+    tr64_t r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\t"
+        "ds_read_b64_tr_b16 %3, %11\n\tds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+        "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
+        : "memory");
+    f0 = join_tr64(r0, r1); f1 = join_tr64(r2, r3); f2 = join_tr64(r4, r5); f3 = join_tr64(r6, r7);
+}
+// two fragments (4 reads)
+__device__ __forceinline__ void tr_read4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, bf16x8& f0, bf16x8& f1) {
+    tr64_t r0, r1, r2, r3;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\t"
+        "ds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+    f0 = join_tr64(r0, r1); f1 = join_tr64(r2, r3);
+}
+
 // ---- host side error channel (thread-local message, C-ABI returns an int code) ----
 void getmi_set_error(const char* fmt, ...);
 #define GETMI_OK 0

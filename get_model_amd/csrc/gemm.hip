@@ -971,29 +971,44 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
     const int nq = nk << 2;
 
     // ---- staging: kind j = 0:X-half0 1:Y-half0 2:Y-half1 3:X-half1; 2 wave-instructions (4 rows each) per kind ----
+    // 32-bit byte offsets from p.X / p.Y (host checks the operands are < 4 GiB) so that the LDS-DMA takes the
+    // "SGPR base + VGPR offset" form and a K-tile step is ONE v_add per instruction (64-bit address arithmetic per
+    // load made this loop instruction-issue bound).  Rows >= M exist only in the very last K-tile: slow path there.
     int srow[2];
-    int scol[4][2];     // global column of this lane's 16-B chunk
+    unsigned soff[4][2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int row = (wave * 2 + jj) * 4 + (lane >> 4);
         srow[jj] = row;
         const int lc = ((lane & 15) ^ wg_swz(row)) * 8;      // local column inside the half image
-        scol[0][jj] = n1_0 + ((lc >> 6) << 7) + (lc & 63);
-        scol[3][jj] = scol[0][jj] + 64;
-        scol[1][jj] = n2_0 + ((lc >> 5) << 6) + (lc & 31);
-        scol[2][jj] = scol[1][jj] + 32;
+        const int c0 = n1_0 + ((lc >> 6) << 7) + (lc & 63), c1 = n2_0 + ((lc >> 5) << 6) + (lc & 31);
+        const size_t m0_ = (size_t)k_begin * BK + row;
+        soff[0][jj] = (unsigned)((m0_ * p.ldx + c0) * 2);
+        soff[3][jj] = (unsigned)((m0_ * p.ldx + c0 + 64) * 2);
+        soff[1][jj] = (unsigned)((m0_ * p.ldy + c1) * 2);
+        soff[2][jj] = (unsigned)((m0_ * p.ldy + c1 + 32) * 2);
     }
+    const unsigned kstep_x = (unsigned)(BK * p.ldx * 2), kstep_y = (unsigned)(BK * p.ldy * 2);
+    const bool ragged = (p.M % BK) != 0;
+    const char* baseX = reinterpret_cast<const char*>(p.X);
+    const char* baseY = reinterpret_cast<const char*>(p.Y);
     // LDS offsets of the four half images inside a buffer
     constexpr int IMG_X0 = 0, IMG_X1 = 16384, IMG_Y0 = 32768, IMG_Y1 = 49152;
 #define W2_ISSUE(t, J)                                                                                        \
     do {                                                                                                      \
         char* b_ = smem + (((t)&1) << 16) + ((J) == 0 ? IMG_X0 : (J) == 3 ? IMG_X1 : (J) == 1 ? IMG_Y0 : IMG_Y1); \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                    \
-            const int m_ = (k_begin + (t)) * BK + srow[jj];                                                   \
-            const void* s_;                                                                                   \
-            if ((J) == 0 || (J) == 3) s_ = (m_ < p.M) ? (const void*)(p.X + (size_t)m_ * p.ldx + scol[J][jj]) : (const void*)g_zero_line; \
-            else s_ = (m_ < p.M) ? (const void*)(p.Y + (size_t)m_ * p.ldy + scol[J][jj]) : (const void*)g_zero_line; \
-            glds16(s_, b_ + (wave * 2 + jj) * 1024);                                                          \
+        const bool isx_ = ((J) == 0 || (J) == 3);                                                             \
+        const char* base_ = isx_ ? baseX : baseY;                                                             \
+        const unsigned ko_ = (unsigned)(t) * (isx_ ? kstep_x : kstep_y);                                      \
+        if (ragged && (k_begin + (t)) == nk_total - 1) {                                                      \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                \
+                const int m_ = (k_begin + (t)) * BK + srow[jj];                                               \
+                const void* s_ = (m_ < p.M) ? (const void*)(base_ + (size_t)(soff[J][jj] + ko_)) : (const void*)g_zero_line; \
+                glds16(s_, b_ + (wave * 2 + jj) * 1024);                                                      \
+            }                                                                                                 \
+        } else {                                                                                              \
+            glds16(base_ + (size_t)(soff[J][0] + ko_), b_ + (wave * 2) * 1024);                               \
+            glds16(base_ + (size_t)(soff[J][1] + ko_), b_ + (wave * 2 + 1) * 1024);                           \
         }                                                                                                     \
     } while (0)
 
@@ -1020,20 +1035,31 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
         if (nk > 1) { W2_ISSUE(1, 0); W2_ISSUE(1, 1); W2_ISSUE(1, 2); }
     }
     bf16x8 fx[4][2], fy0[2][2], fy1[2][2];
+    // (inline-asm transposed reads: see common.h, tr_read8)
+#define W2_TR8(BASE, OFF, I0, I1, F0, F1, F2, F3)                                                            \
+    tr_read8((BASE) + ((OFF)[0][0] ^ ((I0) << 5)), (BASE) + ((OFF)[0][1] ^ ((I0) << 5)),                     \
+             (BASE) + ((OFF)[1][0] ^ ((I0) << 5)), (BASE) + ((OFF)[1][1] ^ ((I0) << 5)),                     \
+             (BASE) + ((OFF)[0][0] ^ ((I1) << 5)), (BASE) + ((OFF)[0][1] ^ ((I1) << 5)),                     \
+             (BASE) + ((OFF)[1][0] ^ ((I1) << 5)), (BASE) + ((OFF)[1][1] ^ ((I1) << 5)), F0, F1, F2, F3)
 #define W2_LOAD_X(IMG)                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)           \
-        fx[i][ks] = join_tr(lds_tr16(buf + (IMG) + (xoff[ks][0] ^ (i << 5))), lds_tr16(buf + (IMG) + (xoff[ks][1] ^ (i << 5))));
+    do {                                                                                                     \
+        const unsigned b_ = lbase + (((unsigned)s & 1u) << 16) + (IMG);                                      \
+        W2_TR8(b_, xoff, 0, 1, fx[0][0], fx[0][1], fx[1][0], fx[1][1]);                                      \
+        W2_TR8(b_, xoff, 2, 3, fx[2][0], fx[2][1], fx[3][0], fx[3][1]);                                      \
+    } while (0);
 #define W2_LOAD_Y(FY, IMG)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)           \
-        FY[i][ks] = join_tr(lds_tr16(buf + (IMG) + (yoff[ks][0] ^ (i << 5))), lds_tr16(buf + (IMG) + (yoff[ks][1] ^ (i << 5))));
+    do {                                                                                                     \
+        const unsigned b_ = lbase + (((unsigned)s & 1u) << 16) + (IMG);                                      \
+        W2_TR8(b_, yoff, 0, 1, FY[0][0], FY[0][1], FY[1][0], FY[1][1]);                                      \
+    } while (0);
 #define W2_MMA(MH, NH, FY)                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int a = 0; a < 4; ++a)           \
         _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                        \
             acc[(MH)*4 + a][(NH)*2 + b] =                                                                    \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(FY[b][ks], fx[a][ks], acc[(MH)*4 + a][(NH)*2 + b], 0, 0, 0);
 
+    const unsigned lbase = lds_addr(smem);
     for (int s = 0; s < nk; ++s) {
-        const char* buf = smem + ((s & 1) << 16);
         const int phi = s << 2;
         wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
         phase_barrier();
@@ -1057,6 +1083,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
 #undef W2_ISSUE
 #undef W2_LOAD_X
 #undef W2_LOAD_Y
+#undef W2_TR8
 #undef W2_MMA
 
     float* out = p.slabs + (size_t)split * p.N1 * p.N2;
@@ -1206,7 +1233,7 @@ static bool wgrad_big(int M, int N1, int N2) {
         g_tile_mode = e ? atoi(e) : 0;
     }
     if (g_tile_mode == 1) return false;
-    return (N1 % 256 == 0) && (N2 % 256 == 0) && M >= 4096;
+    return (N1 % 256 == 0) && (N2 % 256 == 0) && M >= 4096 && (size_t)M * (N1 > N2 ? N1 : N2) * 2 < 0xF0000000ull;
 }
 
 int getmi_wgrad_nsplit(int M, int N1, int N2) {
