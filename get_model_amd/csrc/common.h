@@ -101,6 +101,34 @@ __device__ __forceinline__ void tr_read8(unsigned a0, unsigned a1, unsigned a2, 
         : "memory");
     f0 = join_tr64(r0, r1); f1 = join_tr64(r2, r3); f2 = join_tr64(r4, r5); f3 = join_tr64(r6, r7);
 }
+// issue-only form: 8 reads, NO wait; the destinations are undefined until tr_wait16 / tr_wait24 (which take them
+// as read-write operands, so the compiler cannot touch them earlier: cdna_hip_programming.md 5.7 form (ii)).
+__device__ __forceinline__ void tr_issue8(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5,
+                                          unsigned a6, unsigned a7, tr64_t (&r)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\t"
+        "ds_read_b64_tr_b16 %3, %11\n\tds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+        "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
+        : "memory");
+}
+__device__ __forceinline__ void tr_wait16(tr64_t (&a)[8], tr64_t (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ void tr_wait24(tr64_t (&a)[8], tr64_t (&b)[8], tr64_t (&c)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])
+                 :
+                 : "memory");
+}
+
 // two fragments (4 reads)
 __device__ __forceinline__ void tr_read4(unsigned a0, unsigned a1, unsigned a2, unsigned a3, bf16x8& f0, bf16x8& f1) {
     tr64_t r0, r1, r2, r3;

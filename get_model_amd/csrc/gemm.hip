@@ -1035,23 +1035,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
         if (nk > 1) { W2_ISSUE(1, 0); W2_ISSUE(1, 1); W2_ISSUE(1, 2); }
     }
     bf16x8 fx[4][2], fy0[2][2], fy1[2][2];
-    // (inline-asm transposed reads: see common.h, tr_read8)
-#define W2_TR8(BASE, OFF, I0, I1, F0, F1, F2, F3)                                                            \
-    tr_read8((BASE) + ((OFF)[0][0] ^ ((I0) << 5)), (BASE) + ((OFF)[0][1] ^ ((I0) << 5)),                     \
-             (BASE) + ((OFF)[1][0] ^ ((I0) << 5)), (BASE) + ((OFF)[1][1] ^ ((I0) << 5)),                     \
-             (BASE) + ((OFF)[0][0] ^ ((I1) << 5)), (BASE) + ((OFF)[0][1] ^ ((I1) << 5)),                     \
-             (BASE) + ((OFF)[1][0] ^ ((I1) << 5)), (BASE) + ((OFF)[1][1] ^ ((I1) << 5)), F0, F1, F2, F3)
-#define W2_LOAD_X(IMG)                                                                                       \
-    do {                                                                                                     \
-        const unsigned b_ = lbase + (((unsigned)s & 1u) << 16) + (IMG);                                      \
-        W2_TR8(b_, xoff, 0, 1, fx[0][0], fx[0][1], fx[1][0], fx[1][1]);                                      \
-        W2_TR8(b_, xoff, 2, 3, fx[2][0], fx[2][1], fx[3][0], fx[3][1]);                                      \
-    } while (0);
-#define W2_LOAD_Y(FY, IMG)                                                                                   \
-    do {                                                                                                     \
-        const unsigned b_ = lbase + (((unsigned)s & 1u) << 16) + (IMG);                                      \
-        W2_TR8(b_, yoff, 0, 1, FY[0][0], FY[0][1], FY[1][0], FY[1][1]);                                      \
-    } while (0);
+    // (inline-asm transposed reads: see common.h).  All reads of a phase are issued, then ONE lgkmcnt wait.
+#define W2_ADDR8(BASE, OFF, I0, I1)                                                                          \
+    (BASE) + ((OFF)[0][0] ^ ((I0) << 5)), (BASE) + ((OFF)[0][1] ^ ((I0) << 5)),                              \
+    (BASE) + ((OFF)[1][0] ^ ((I0) << 5)), (BASE) + ((OFF)[1][1] ^ ((I0) << 5)),                              \
+    (BASE) + ((OFF)[0][0] ^ ((I1) << 5)), (BASE) + ((OFF)[0][1] ^ ((I1) << 5)),                              \
+    (BASE) + ((OFF)[1][0] ^ ((I1) << 5)), (BASE) + ((OFF)[1][1] ^ ((I1) << 5))
+#define W2_JOIN_X(R, I0)                                                                                     \
+    fx[I0][0] = join_tr64(R[0], R[1]); fx[I0][1] = join_tr64(R[2], R[3]);                                    \
+    fx[(I0) + 1][0] = join_tr64(R[4], R[5]); fx[(I0) + 1][1] = join_tr64(R[6], R[7]);
+#define W2_JOIN_Y(FY, R)                                                                                     \
+    FY[0][0] = join_tr64(R[0], R[1]); FY[0][1] = join_tr64(R[2], R[3]);                                      \
+    FY[1][0] = join_tr64(R[4], R[5]); FY[1][1] = join_tr64(R[6], R[7]);
 #define W2_MMA(MH, NH, FY)                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int a = 0; a < 4; ++a)           \
         _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                        \
@@ -1061,29 +1056,45 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
     const unsigned lbase = lds_addr(smem);
     for (int s = 0; s < nk; ++s) {
         const int phi = s << 2;
+        const unsigned bb = lbase + (((unsigned)s & 1u) << 16);
+        tr64_t ra[8], rb[8], rc[8];
+        // ---- P1: X-half0 + Y-half0 ----
         wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
         phase_barrier();
-        W2_LOAD_X(IMG_X0)
-        W2_LOAD_Y(fy0, IMG_Y0)
+        tr_issue8(W2_ADDR8(bb + IMG_X0, xoff, 0, 1), ra);
+        tr_issue8(W2_ADDR8(bb + IMG_X0, xoff, 2, 3), rb);
+        tr_issue8(W2_ADDR8(bb + IMG_Y0, yoff, 0, 1), rc);
         if (s + 1 < nk) W2_ISSUE(s + 1, 3);
+        tr_wait24(ra, rb, rc);
+        W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2) W2_JOIN_Y(fy0, rc)
         W2_MMA(0, 0, fy0)
+        // ---- P2: Y-half1 ----
         wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
         phase_barrier();
-        W2_LOAD_Y(fy1, IMG_Y1)
+        {
+            bf16x8 t0, t1, t2, t3;
+            tr_read8(W2_ADDR8(bb + IMG_Y1, yoff, 0, 1), t0, t1, t2, t3);
+            fy1[0][0] = t0; fy1[0][1] = t1; fy1[1][0] = t2; fy1[1][1] = t3;
+        }
         if (s + 2 < nk) W2_ISSUE(s + 2, 0);
         W2_MMA(0, 1, fy1)
+        // ---- P3: X-half1 ----
         wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
         phase_barrier();
-        W2_LOAD_X(IMG_X1)
+        tr_issue8(W2_ADDR8(bb + IMG_X1, xoff, 0, 1), ra);
+        tr_issue8(W2_ADDR8(bb + IMG_X1, xoff, 2, 3), rb);
         if (s + 2 < nk) W2_ISSUE(s + 2, 1);
+        tr_wait16(ra, rb);
+        W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2)
         W2_MMA(1, 1, fy1)
+        // ---- P4 ----
         if (s + 2 < nk) W2_ISSUE(s + 2, 2);
         W2_MMA(1, 0, fy0)
     }
 #undef W2_ISSUE
-#undef W2_LOAD_X
-#undef W2_LOAD_Y
-#undef W2_TR8
+#undef W2_ADDR8
+#undef W2_JOIN_X
+#undef W2_JOIN_Y
 #undef W2_MMA
 
     float* out = p.slabs + (size_t)split * p.N1 * p.N2;
