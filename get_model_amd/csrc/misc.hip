@@ -300,6 +300,45 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + c) = s;
 }
 
+// Streaming form for N % 8 == 0, ld % 8 == 0, 16-byte aligned X: a block is 64 column chunks (16 B each) x 4 row
+// lanes, every thread keeps 8 row loads in flight (HBM-bound: 8 waves/CU x 8 x 1 KiB outstanding).
+__global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const bf16_t* __restrict__ X, float* __restrict__ partial,
+                                                               int M, int N, int ld) {
+    __shared__ __attribute__((aligned(16))) float red[4][64][8];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + tx) * 8;
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    auto add = [&](const uint4& v) {
+        s[0] += bf2f(v.x & 0xffff); s[1] += bf2f(v.x >> 16); s[2] += bf2f(v.y & 0xffff); s[3] += bf2f(v.y >> 16);
+        s[4] += bf2f(v.z & 0xffff); s[5] += bf2f(v.z >> 16); s[6] += bf2f(v.w & 0xffff); s[7] += bf2f(v.w >> 16);
+    };
+    if (c < N) {
+        const int stride = gridDim.y * 4;
+        const bf16_t* px = X + c;
+        int r = blockIdx.y * 4 + ty;
+        for (; r + 7 * stride < M; r += 8 * stride) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(px + (size_t)(r + u * stride) * ld);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(v[u]);
+        }
+        for (; r < M; r += stride) add(*reinterpret_cast<const uint4*>(px + (size_t)r * ld));
+    }
+    *reinterpret_cast<float4*>(&red[ty][tx][0]) = make_float4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<float4*>(&red[ty][tx][4]) = make_float4(s[4], s[5], s[6], s[7]);
+    __syncthreads();
+    if (ty == 0 && c < N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = (red[0][tx][i] + red[1][tx][i]) + (red[2][tx][i] + red[3][tx][i]);
+        float* o = partial + (size_t)blockIdx.y * N + c;
+        *reinterpret_cast<float4*>(o) = make_float4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    }
+}
+
 // ================================================================================================
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
                          hipStream_t st);
@@ -443,9 +482,14 @@ int getmi_colsum_bf16_impl(const bf16_t* X, float* out, int accumulate, int M, i
                            hipStream_t st) {
     GETMI_CHECK_ARG(N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
     GETMI_CHECK_ARG(ws_bytes >= getmi_colsum_workspace_bytes_impl(N), "colsum: workspace too small");
-    const int gy = M < 256 ? M : 256;
+    int gy = M < 256 ? M : 256;
     float* partial = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 1023) / 1024, gy), dim3(256), 0, st, X, partial, M, N, ld);
+    if (N % 8 == 0 && ld % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && M >= 1024) {
+        gy = 256;   // 4 rows per block pass
+        hipLaunchKernelGGL(colsum_bf16_wide_kernel, dim3((N + 511) / 512, gy), dim3(256), 0, st, X, partial, M, N, ld);
+    } else {
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 1023) / 1024, gy), dim3(256), 0, st, X, partial, M, N, ld);
+    }
     GETMI_CHECK_LAUNCH("colsum");
     return getmi_colreduce_impl(partial, out, nullptr, nullptr, gy, N, accumulate, st);
 }

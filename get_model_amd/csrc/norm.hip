@@ -68,17 +68,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         ab[v] = ag[v];
         az[v] = ag[v];
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+    // software pipeline over this wave's rows: the next row's x / dy / dres loads are issued before the current
+    // row's two wave reductions, so the reduction latency is hidden behind HBM traffic.
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    float4 nx[NV], nr[NV];
+    uint2 nd[NV];
+    float nmu = 0.f, nrs = 0.f;
+    auto issue = [&](int r) {
+        nmu = mean[r];
+        nrs = rstd[r];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            nx[v] = *reinterpret_cast<const float4*>(x + (size_t)r * D + (v * 64 + lane) * 4);
+            nd[v] = *reinterpret_cast<const uint2*>(dy + (size_t)r * D + (v * 64 + lane) * 4);
+            if (dres) nr[v] = *reinterpret_cast<const float4*>(dres + (size_t)r * D + (v * 64 + lane) * 4);
+        }
+    };
+    if (row < M) issue(row);
+    for (; row < M; row += stride) {
+        const float mu = nmu, rs = nrs;
         const float sc = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
-        float4 xh[NV], d[NV];
+        float4 xh[NV], d[NV], rv[NV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * D + (v * 64 + lane) * 4);
-            const uint2 dv = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + (v * 64 + lane) * 4);
+            const float4 xv = nx[v];
+            const uint2 dv = nd[v];
+            rv[v] = dres ? nr[v] : make_float4(0.f, 0.f, 0.f, 0.f);
             xh[v] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
             d[v] = make_float4(bf2f(dv.x & 0xffff), bf2f(dv.x >> 16), bf2f(dv.y & 0xffff), bf2f(dv.y >> 16));
+        }
+        if (row + stride < M) issue(row + stride);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
             ag[v].x += d[v].x * xh[v].x; ag[v].y += d[v].y * xh[v].y;
             ag[v].z += d[v].z * xh[v].z; ag[v].w += d[v].w * xh[v].w;
             ab[v].x += d[v].x; ab[v].y += d[v].y; ab[v].z += d[v].z; ab[v].w += d[v].w;
@@ -92,10 +115,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int v = 0; v < NV; ++v) {
             float4 o = make_float4(rs * (d[v].x - c1 - xh[v].x * c2), rs * (d[v].y - c1 - xh[v].y * c2),
                                    rs * (d[v].z - c1 - xh[v].z * c2), rs * (d[v].w - c1 - xh[v].w * c2));
-            if (dres) {
-                const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * D + (v * 64 + lane) * 4);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
+            o.x += rv[v].x; o.y += rv[v].y; o.z += rv[v].z; o.w += rv[v].w;
             *reinterpret_cast<float4*>(dx + (size_t)row * D + (v * 64 + lane) * 4) = o;
             if (dz) {
                 const float4 z = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
@@ -117,19 +137,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out_k[c] (+)= sum_r partial[k][r][c]   for k = blockIdx.y; 64 columns x 16 row groups per block
+// out_k[c] (+)= sum_r partial[k][r][c]   for k = blockIdx.y; 32 columns x 32 row groups per block, 4 loads in flight
 __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ partial, float* out0, float* out1,
                                                          float* out2, int R, int C, int accumulate) {
-    __shared__ float red[16][64];
+    __shared__ float red[32][33];
     const int k = blockIdx.y;
     float* out = k == 0 ? out0 : (k == 1 ? out1 : out2);
     if (out == nullptr) return;   // block-uniform
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    if (c < C)
-        for (int r = ty; r < R; r += 16) s += partial[((size_t)k * R + r) * C + c];
+    if (c < C) {
+        const float* p = partial + (size_t)k * R * C + c;
+        int r = ty;
+        for (; r + 96 < R; r += 128) {
+            const float a0 = p[(size_t)r * C], a1 = p[(size_t)(r + 32) * C];
+            const float a2 = p[(size_t)(r + 64) * C], a3 = p[(size_t)(r + 96) * C];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; r < R; r += 32) s += p[(size_t)r * C];
+    }
     red[ty][tx] = s;
+    __syncthreads();
+    if (ty < 16) red[ty][tx] += red[ty + 16][tx];
     __syncthreads();
     if (ty == 0 && c < C) {
         float t = 0.f;
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict
 
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
                          hipStream_t st) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 63) / 64, 3), dim3(1024), 0, st, partial, out0, out1, out2, R, C,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((C + 31) / 32, 3), dim3(1024), 0, st, partial, out0, out1, out2, R, C,
                        accumulate);
     GETMI_CHECK_LAUNCH("colreduce");
     return GETMI_OK;

@@ -8,7 +8,8 @@ gradients.  Differences by design:
     one bucket per encoder block (~28 MB at 12Lx768), so a bucket completes as soon as its block's fused
     backward returns and its all-reduce runs on RCCL's stream under the remaining backward;
   * `param.grad` are views into the buckets: no flatten/unflatten copies, and the optimizer reads the reduced
-    gradients in place;
+    gradients in place; the weight-gradient GEMMs write their result directly into the bucket slot
+    (`param.getmi_grad_buffer`), which autograd then adopts as `param.grad` without a copy or an add;
   * no unused-parameter graph walk: parameters that received no gradient are simply reduced as zeros.
 Works with any backend (`gloo` on CPU for the tests).
 """
@@ -54,30 +55,41 @@ class GradBuckets:
             self.buckets.append(cur)
         self.flat = []
         self._bucket_of = {}
-        self._pending = []
+        self._view = {}
         for bi, params in enumerate(self.buckets):
-            total = sum(p.numel() for p in params)
+            pad = lambda n: (n + 63) // 64 * 64     # every slot starts on a 256-byte boundary (kernel stores need 16 B)
+            total = sum(pad(p.numel()) for p in params)
             dev, dt = params[0].device, params[0].dtype
             flat = torch.zeros(total, dtype=dt, device=dev)
             off = 0
             for p in params:
-                p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                view = flat[off:off + p.numel()].view_as(p)
+                off += pad(p.numel())
                 self._bucket_of[p] = bi
+                self._view[p] = view
+                # the fused backward (functional.grad_buffer) writes weight gradients straight into this slot and
+                # autograd adopts the returned alias as p.grad: no zero fill, no `grad += new` pass per step.
+                p.getmi_grad_buffer = view
+                p.grad = None
             self.flat.append(flat)
-        self._remaining = [len(b) for b in self.buckets]
-        self._handles = []
+        self.sync = True      # False: accumulate locally (micro-batches); the exchange happens in finish()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.zero_grad()
 
     # ---- per step ----
     def zero_grad(self):
-        for f in self.flat:
-            f.zero_()
+        """Start a new step: gradients are dropped (set to None), not zero-filled; slots of parameters that end
+        the step without a gradient are zeroed in finish()."""
+        for b in self.buckets:
+            for p in b:
+                p.grad = None
         self._remaining = [len(b) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._handles = []
 
     def _launch(self, bi):
+        self._launched[bi] = True
         if self.world == 1:
             return
         flat = self.flat[bi]
@@ -87,16 +99,27 @@ class GradBuckets:
             self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat))
 
     def _on_grad(self, p):
+        view = self._view[p]
+        g = p.grad
+        if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
+            view.copy_(g)          # small parameters (biases, norms, tokens) and anything not written in place
+            p.grad = view
         bi = self._bucket_of[p]
         self._remaining[bi] -= 1
-        if self._remaining[bi] == 0:
+        if self._remaining[bi] == 0 and self.sync:
             self._launch(bi)
 
     def finish(self):
-        """Call after backward: launches buckets whose parameters got no gradient (unused), then waits."""
-        for bi, r in enumerate(self._remaining):
-            if r > 0:
-                self._remaining[bi] = 0
+        """Call after backward: zero-fills the slots of parameters that got no gradient (unused), launches the
+        buckets that are still pending, then waits for every exchange."""
+        for b in self.buckets:
+            for p in b:
+                if p.grad is None:
+                    view = self._view[p]
+                    view.zero_()
+                    p.grad = view
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
                 self._launch(bi)
         for h, flat in self._handles:
             h.wait()
@@ -113,5 +136,6 @@ def broadcast_parameters(module, src=0, process_group=None):
     """Make every rank start from rank `src`'s weights (what DDP does at construction)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
+    with torch.no_grad():       # on the tensors themselves (not .data): bumps _version, so cached bf16 copies refresh
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=process_group)

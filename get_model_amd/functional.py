@@ -13,6 +13,8 @@ Granularity follows the reference's module boundaries (`re
 Numerics: fp32 master weights and fp32 residual stream; bf16 MFMA operands with fp32 accumulation; bf16
 saved activations.  There is no eager fallback: CPU tensors raise.
 """
+import weakref
+
 import torch
 
 from . import kernels as K
@@ -39,10 +41,12 @@ class _WeightCache:
         key = (id(w), kind)
         hit = self._c.get(key)
         tag = (w._version, w.data_ptr(), tuple(w.shape))
-        if hit is not None and hit[0] == tag:
+        # id() and data_ptr() are both recycled once a model is freed: the entry also pins the identity of the
+        # parameter it was made from (weak reference, dropped together with the parameter).
+        if hit is not None and hit[0] == tag and hit[2]() is w:
             return hit[1]
         val = make(w.detach())
-        self._c[key] = (tag, val)
+        self._c[key] = (tag, val, weakref.ref(w, lambda _r, k=key, c=self._c: c.pop(k, None) if (k in c and c[k][2]() is None) else None))
         return val
 
     def clear(self):
@@ -58,6 +62,16 @@ def w_bf16(w):
 
 def w_bf16_t(w):
     return WEIGHTS.get(w, "t", lambda t: K.cast_transpose(t.contiguous()))
+
+
+def grad_buffer(w):
+    """Destination for a weight gradient: a fresh alias of the DDP bucket slot (ddp.GradBuckets sets
+    `getmi_grad_buffer`) when the parameter has no gradient yet, so autograd adopts it as `w.grad` with no copy;
+    None (-> a new tensor that autograd adds into w.grad) otherwise, e.g. on later micro-batches."""
+    buf = getattr(w, "getmi_grad_buffer", None)
+    if buf is None or w.grad is not None:
+        return None
+    return buf.view(buf.shape)
 
 
 def _pad_to(n, m):
@@ -170,21 +184,21 @@ class EncoderBlock(torch.autograd.Function):
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
         K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)  # (dz2 @ W2) * gelu'(u), + column sums
-        dfc2_w = K.gemm_wgrad(dz2, g) if need[12] else None
+        dfc2_w = K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w)) if need[12] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
-        dfc1_w = K.gemm_wgrad(du, h2) if need[10] else None
+        dfc1_w = K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w)) if need[10] else None
         dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
                                                            want_dbias=True)
         # ---- attention branch ----
         da = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dz1, w_bf16_t(proj_w), da)                       # dz1 @ Wproj
-        dproj_w = K.gemm_wgrad(dz1, a) if need[6] else None
+        dproj_w = K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w)) if need[6] else None
         dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
-        dqkv_w = K.gemm_wgrad(dqkv, h1) if need[3] else None
+        dqkv_w = K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w)) if need[3] else None
         dq_bias = dv_bias = None
         if need[4]:
             dq_bias = K.colsum_bf16(dqkv[:, :D])          # the K third has no bias (model/transformer.py:53)

@@ -102,3 +102,38 @@ def test_frozen_layers_get_no_grad():
     for n, p in model.named_parameters():
         frozen = n.startswith("encoder.blocks.0") or n.startswith("region_embed")
         assert (p.grad is None) == frozen, n
+
+
+def test_grad_buckets_hold_the_same_gradients_without_copies():
+    """ddp.GradBuckets: weight gradients are written in place into the flat buckets (param.grad aliases its slot),
+    bit-identical to the bucket-free run; a second backward without zero_grad accumulates (micro-batches)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd.config import build_model, region_model_yaml
+    from get_model_amd.ddp import GradBuckets
+    c = load_case("ft_L2_B2_N200_eval")
+    _, _, ref = run_hip(c, False)
+    model = build_model(region_model_yaml("finetune", num_layers=2))
+    model.load_state_dict(c["sd"])
+    model = model.cuda().eval()
+    buckets = GradBuckets(model)
+    batch = {k: v.cuda() for k, v in c["batch"].items()}
+
+    def backward_once():
+        out = model(**model.get_input(batch))
+        pred, obs = model.before_loss(out, batch)
+        model.after_loss(model.loss(pred, obs)).backward()
+
+    for f in buckets.flat:
+        f.fill_(float("nan"))           # stale contents must never leak into a gradient
+    buckets.zero_grad()
+    backward_once()
+    buckets.finish()
+    lo = {f.data_ptr(): f.data_ptr() + f.numel() * 4 for f in buckets.flat}
+    for n, p in model.named_parameters():
+        assert any(a <= p.grad.data_ptr() < b for a, b in lo.items()), f"{n}: grad is not a bucket view"
+        assert torch.equal(p.grad, ref[n]), n
+    backward_once()                     # no zero_grad: accumulate
+    buckets.finish()
+    for n, p in model.named_parameters():
+        torch.testing.assert_close(p.grad, 2 * ref[n], rtol=1e-6, atol=1e-7)
