@@ -13,6 +13,7 @@ Granularity follows the reference's module boundaries (`re
 Numerics: fp32 master weights and fp32 residual stream; bf16 MFMA operands with fp32 accumulation; bf16
 saved activations.  There is no eager fallback: CPU tensors raise.
 """
+import os
 import weakref
 
 import torch
@@ -72,6 +73,43 @@ def grad_buffer(w):
     if buf is None or w.grad is not None:
         return None
     return buf.view(buf.shape)
+
+
+# Optional (GETMI_WGRAD_STREAM=1): run the weight-gradient GEMMs, which have no consumer inside backward, on a
+# second HIP stream next to the data-gradient chain so that they fill the CUs a 603-tile (N = 768) GEMM leaves
+# idle in its last partial round.  Measured on MI355X at the bench shape it LOSES 3 % (42.1 vs 40.8 ms/step):
+# both kernels are 1-workgroup-per-CU designs that want the whole L2/LDS, so it is off by default.  Joined
+# before the block's backward returns (gradients are then ordered on the main stream for autograd, the DDP
+# hooks and the optimizer).
+_SIDE = {}
+_USE_SIDE = os.environ.get("GETMI_WGRAD_STREAM", "0") == "1"
+
+
+class _SideStream:
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        self.side = None
+        if _USE_SIDE:
+            key = (device.index, self.main.cuda_stream)
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device)
+            self.side = _SIDE[key]
+        self.used = False
+
+    def run(self, fn):
+        """fn() on the side stream, after everything issued so far on the main stream."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        self.used = True
+        return out
+
+    def join(self):
+        if self.used:
+            self.main.wait_stream(self.side)
+            self.used = False
 
 
 def _pad_to(n, m):
@@ -179,32 +217,36 @@ class EncoderBlock(torch.autograd.Function):
         dev = dx_out.device
         need = ctx.needs_input_grad
         dx_out = dx_out.reshape(M, D).contiguous()
+        side = _SideStream(dev)
         # ---- MLP branch ----
+        # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
+        #  operand, so it waits only for the operand's producer and the two run side by side)
         dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+        dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
         K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)  # (dz2 @ W2) * gelu'(u), + column sums
-        dfc2_w = K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w)) if need[12] else None
+        dfc1_w = side.run(lambda: K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w))) if need[10] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
-        dfc1_w = K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w)) if need[10] else None
         dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
                                                            want_dbias=True)
         # ---- attention branch ----
+        dproj_w = side.run(lambda: K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w))) if need[6] else None
         da = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dz1, w_bf16_t(proj_w), da)                       # dz1 @ Wproj
-        dproj_w = K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w)) if need[6] else None
         dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
+        dqkv_w = side.run(lambda: K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w))) if need[3] else None
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
-        dqkv_w = K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w)) if need[3] else None
         dq_bias = dv_bias = None
         if need[4]:
             dq_bias = K.colsum_bf16(dqkv[:, :D])          # the K third has no bias (model/transformer.py:53)
         if need[5]:
             dv_bias = K.colsum_bf16(dqkv[:, 2 * D:])
         dx_in, _, dn1w, dn1b, _ = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid)
+        side.join()
         return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
                 dfc1_b, dfc2_w, dfc2_b, None, None, None, None)
 
