@@ -187,47 +187,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
     }
 }
 
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                  float* __restrict__ delta, int B, int T, int H) {
-    const size_t n = (size_t)B * T * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int h = (int)(i % H);
-        const size_t bt = i / H;
-        const int t = (int)(bt % T);
-        const size_t b = bt / T;
-        const uint4* po = reinterpret_cast<const uint4*>(o + i * HD);
-        const uint4* pd = reinterpret_cast<const uint4*>(dout + i * HD);
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint4 a = po[k], d = pd[k];
-            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                acc += bf2f(aw[w] & 0xffff) * bf2f(dw[w] & 0xffff) + bf2f(aw[w] >> 16) * bf2f(dw[w] >> 16);
-        }
-        delta[(b * H + h) * T + t] = acc;
-    }
-}
-
 struct AttnBwdArgs {
     const bf16_t* qkv;
+    const bf16_t* out;    // [B,T,H*64] forward output (for delta = rowsum(dO * O))
     const bf16_t* dout;   // [B,T,H*64]
     const float* lse;     // [B,H,T]
-    const float* delta;   // [B,H,T]
     bf16_t* dqkv;         // [B,T,3,H,64]
     float* dq_acc;        // [B,T,H,64] fp32, only when T > 256
     int B, T, H;
     float scale;
 };
 
-// LDS map (bytes)
+// LDS map (bytes).  Everything a workgroup reads is staged ONCE per 256-query chunk (for T <= 256: once), so no
+// LDS-DMA is in flight inside the slice loop: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read that may
+// alias an in-flight global_load_lds, which in the earlier per-slice double-buffered version exposed the full
+// global latency seven times per workgroup (measured 299 us -> see DESIGN.md).
 #define BW_KIMG 0                 // [256 keys][128 B]
-#define BW_QD 32768               // 2 x (Q slice 4 KB | dO slice 4 KB)
-#define BW_DS 49152               // [256 keys][32 q] bf16 (64-B rows, halves swapped by (key>>3)&1)
-#define BW_ST 65536               // 2 x (lse'[32] | delta[32]) fp32
-#define BW_LDS (65536 + 512)
+#define BW_QIMG 32768             // [256 q][128 B]
+#define BW_DOIMG 65536            // [256 q][128 B]
+#define BW_DS 98304               // 2 x [256 keys][32 q] bf16 (64-B rows, halves swapped by (key>>3)&1)
+#define BW_ST 131072              // lse'[256] | delta[256] fp32
+#define BW_LDS (131072 + 2048)
 
 __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,24 +220,28 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     const size_t rs = (size_t)3 * H * HD;
     const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
     const bf16_t* dobase = p.dout + (size_t)b * T * (H * HD) + h * HD;
+    const bf16_t* obase = p.out + (size_t)b * T * (H * HD) + h * HD;
     const float* lse = p.lse + ((size_t)b * H + h) * T;
-    const float* delta = p.delta + ((size_t)b * H + h) * T;
     const int key_base = kbi * 256;
     const int r = lane & 31, h2 = lane >> 5;
     const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
     const int mykey = key_base + wave * 32 + r;          // this lane's key (column of S, dP)
     const bool wave_active = (key_base + wave * 32) < T;  // wave-uniform
+    const bool wave_ragged = (key_base + wave * 32 + 32) > T;
     const float c2 = p.scale * LOG2E;
     const float inv_scale = 1.0f / p.scale;
+    const int nks = min(8, (T - key_base + 31) >> 5);     // 32-key groups of this workgroup that hold a valid key
 
-    // ---- K image: 256 rows = 32 wave-instructions, 4 per wave ----
+    // ---- K image: 256 rows = 32 wave-instructions, 4 per wave (rows past T clamp to T-1: finite, and their dS is 0) ----
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int I = wave * 4 + j;
-        const int row = I * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz128(row);
-        const int key = min(key_base + row, T - 1);
-        glds16(base + (size_t)key * rs + H * HD + chunk * 8, smem + BW_KIMG + I * 1024);
+        if (I * 8 < nks * 32) {
+            const int row = I * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz128(row);
+            const int key = min(key_base + row, T - 1);
+            glds16(base + (size_t)key * rs + H * HD + chunk * 8, smem + BW_KIMG + I * 1024);
+        }
     }
     // ---- V fragments of this wave's 32 keys (second operand of dP = dO.V^T): V[key r][16kk + 8h2 ..] ----
     bf16x8 vf[4];
@@ -268,134 +252,171 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             vf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)key * rs + 2 * H * HD + kk * 16 + h2 * 8);
     }
 
-    const int nslice = (T + 31) >> 5;
-    auto stage = [&](int buf, int sl) {
-        // Q slice: waves 0-3, dO slice: waves 4-7; 8 rows (1 KiB) per wave-instruction
-        const int w4 = wave & 3;
-        const int row = w4 * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz128(row);
-        const int q = min(sl * 32 + row, T - 1);
-        char* dst = smem + BW_QD + buf * 8192 + (wave >> 2) * 4096 + w4 * 1024;
-        const bf16_t* src = (wave < 4) ? (base + (size_t)q * rs + chunk * 8)
-                                       : (dobase + (size_t)q * (H * HD) + chunk * 8);
-        glds16(src, dst);
-        if (tid < 64) {
-            const int qi = sl * 32 + (tid & 31);
-            float v;
-            if (tid < 32) v = (qi < T) ? lse[qi] * inv_scale : INFINITY;
-            else v = (qi < T) ? delta[qi] : 0.f;
-            reinterpret_cast<float*>(smem + BW_ST + buf * 256)[tid] = v;
-        }
-    };
-
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+    bf16x8 kfr[4];   // this wave's K rows as the B operand of S = Q.K^T           (slice-invariant, kept in VGPRs)
+    bf16x8 ktf[8];   // K^T fragments of all 256 keys for this wave's dQ d-block   (slice-invariant, kept in VGPRs)
+    float* stf = reinterpret_cast<float*>(smem + BW_ST);
+    int dsbuf = 0;
 
-    stage(0, 0);
-    __syncthreads();
-    for (int sl = 0; sl < nslice; ++sl) {
-        const int cur = sl & 1;
-        if (sl + 1 < nslice) stage(cur ^ 1, sl + 1);
-        const char* qimg = smem + BW_QD + cur * 8192;
-        const char* doimg = qimg + 4096;
-        const float* st = reinterpret_cast<const float*>(smem + BW_ST + cur * 256);
-        if (wave_active) {
-            // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2
-            f32x16 s, dp;
+    for (int qc = 0; qc < T; qc += 256) {
+        if (qc) __syncthreads();   // every wave has left the previous chunk's images
+        const int nrow = min(256, ((T - qc + 31) >> 5) << 5);   // rows of this chunk the slices will read
+        // ---- Q chunk: waves 0-3, dO chunk: waves 4-7; 8 rows (1 KiB) per wave-instruction, 8 per wave ----
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 a = *reinterpret_cast<const float4*>(st + 8 * g4 + 4 * h2);
-                const float4 d = *reinterpret_cast<const float4*>(st + 32 + 8 * g4 + 4 * h2);
-                s[4 * g4] = -a.x; s[4 * g4 + 1] = -a.y; s[4 * g4 + 2] = -a.z; s[4 * g4 + 3] = -a.w;
-                dp[4 * g4] = -d.x; dp[4 * g4 + 1] = -d.y; dp[4 * g4 + 2] = -d.z; dp[4 * g4 + 3] = -d.w;
+        for (int j = 0; j < 8; ++j) {
+            const int II = (wave & 3) * 8 + j;
+            if (II * 8 < nrow) {
+                const int row = II * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ swz128(row);
+                const int q = min(qc + row, T - 1);
+                const bf16_t* src = (wave < 4) ? (base + (size_t)q * rs + chunk * 8)
+                                               : (dobase + (size_t)q * (H * HD) + chunk * 8);
+                glds16(src, smem + (wave < 4 ? BW_QIMG : BW_DOIMG) + II * 1024);
             }
+        }
+        // ---- lse' = lse / scale (+inf past T -> P = 0) and delta = rowsum(dO * O): two threads per query ----
+        {
+            const int qi = qc + (tid >> 1);
+            float acc = 0.f;
+            if (qi < T) {
+                const uint4* po = reinterpret_cast<const uint4*>(obase + (size_t)qi * (H * HD) + (tid & 1) * 32);
+                const uint4* pd = reinterpret_cast<const uint4*>(dobase + (size_t)qi * (H * HD) + (tid & 1) * 32);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ch = ((2 * kk + h2) ^ swz128(r)) << 4;
-                const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(qimg + r * 128 + ch);
-                const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(doimg + r * 128 + ch);
-                const int krow = wave * 32 + r;
-                const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(
-                    smem + BW_KIMG + krow * 128 + (((2 * kk + h2) ^ swz128(krow)) << 4));
-                s = MFMA32(qfr, kfr, s);      // S'[q][key] = Q.K^T - lse/scale
-                dp = MFMA32(dofr, vf[kk], dp);  // dP'[q][key] = dO.V^T - delta
-            }
-            const bool kvalid = mykey < T;
+                for (int k = 0; k < 4; ++k) {
+                    const uint4 a = po[k], d = pd[k];
+                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pr = kvalid ? __builtin_amdgcn_exp2f(s[i] * c2) : 0.f;
-                s[i] = pr;                       // P
-                dp[i] = pr * dp[i] * p.scale;    // dS (already scaled for dQ / dK)
-            }
-            bf16x8 pf[2], dsf[2];
-            pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
-            pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
-            dsf[0] = pack8(dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[7]);
-            dsf[1] = pack8(dp[8], dp[9], dp[10], dp[11], dp[12], dp[13], dp[14], dp[15]);
-            // dV^T[d][key] += dO^T[d][q].P[q][key] ; dK^T[d][key] += Q^T[d][q].dS[q][key]
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int ss = 0; ss < 2; ++ss) {
-                    const int qlo = 16 * ss + 4 * h2 + qq;
-                    const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
-                    const bf16x8 dot = join_tr_a(lds_tr16a(doimg + off128(qlo, col)),
-                                                 lds_tr16a(doimg + off128(qlo + 8, col)));
-                    const bf16x8 qt = join_tr_a(lds_tr16a(qimg + off128(qlo, col)),
-                                                lds_tr16a(qimg + off128(qlo + 8, col)));
-                    dv[db] = MFMA32(dot, pf[ss], dv[db]);
-                    dk[db] = MFMA32(qt, dsf[ss], dk[db]);
+                    for (int w = 0; w < 4; ++w)
+                        acc += bf2f(aw[w] & 0xffff) * bf2f(dw[w] & 0xffff) + bf2f(aw[w] >> 16) * bf2f(dw[w] >> 16);
                 }
-            // dS^T image: row = key (wave*32 + r), 32 q per row (64 B); 32-B halves swapped when (key>>3)&1
-            {
-                const int krow = wave * 32 + r;
-                char* row = smem + BW_DS + krow * 64;
-                const int hs = (krow >> 3) & 1;
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            // stored negated: they are the initial values of the S' / dP' accumulators
+            if (tid & 1) stf[tid >> 1] = (qi < T) ? -lse[qi] * inv_scale : -INFINITY;
+            else stf[256 + (tid >> 1)] = -acc;
+        }
+        __syncthreads();
+        if (qc == 0) {
+            const int krow = wave * 32 + r;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                kfr[kk] = *reinterpret_cast<const bf16x8*>(smem + BW_KIMG + krow * 128 +
+                                                           (((2 * kk + h2) ^ swz128(krow)) << 4));
+            const int kcol = (wave >> 1) * 16 + 4 * pp;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int klo = ks * 32 + 8 * gi + qq;
+                ktf[ks] = join_tr_a(lds_tr16a(smem + BW_KIMG + off128(klo, kcol)),
+                                    lds_tr16a(smem + BW_KIMG + off128(klo + 4, kcol)));
+            }
+        }
+        const int nsl = nrow >> 5;
+        for (int sl = 0; sl < nsl; ++sl) {
+            const char* qimg = smem + BW_QIMG + sl * 4096;
+            const char* doimg = smem + BW_DOIMG + sl * 4096;
+            const float* st = stf + sl * 32;
+            char* dsimg = smem + BW_DS + dsbuf * 16384;
+            if (wave_active) {
+                // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2
+                f32x16 s, dp;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int q = 8 * g4 + 4 * h2;   // first of 4 consecutive query rows
-                    const int byte = ((((q >> 4) ^ hs) << 5) | ((q & 15) << 1));
-                    *reinterpret_cast<uint2*>(row + byte) =
-                        pack4bf(dp[4 * g4], dp[4 * g4 + 1], dp[4 * g4 + 2], dp[4 * g4 + 3]);
+                    const float4 a = *reinterpret_cast<const float4*>(st + 8 * g4 + 4 * h2);
+                    const float4 d = *reinterpret_cast<const float4*>(st + 256 + 8 * g4 + 4 * h2);
+                    s[4 * g4] = a.x; s[4 * g4 + 1] = a.y; s[4 * g4 + 2] = a.z; s[4 * g4 + 3] = a.w;
+                    dp[4 * g4] = d.x; dp[4 * g4 + 1] = d.y; dp[4 * g4 + 2] = d.z; dp[4 * g4 + 3] = d.w;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = ((2 * kk + h2) ^ swz128(r)) << 4;
+                    const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(qimg + r * 128 + ch);
+                    const bf16x8 dofr = *reinterpret_cast<const bf16x8*>(doimg + r * 128 + ch);
+                    s = MFMA32(qfr, kfr[kk], s);      // S'[q][key] = Q.K^T - lse/scale
+                    dp = MFMA32(dofr, vf[kk], dp);    // dP'[q][key] = dO.V^T - delta
+                }
+                // (VALU-lean: the softmax scale of dS is applied once to the dK / dQ results, not per element)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[i] = __builtin_amdgcn_exp2f(s[i] * c2);   // P
+                    dp[i] = s[i] * dp[i];                       // dS / scale
+                }
+                if (wave_ragged) {   // wave-uniform: only the wave that straddles T has padded keys
+                    const bool kvalid = mykey < T;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s[i] = kvalid ? s[i] : 0.f;
+                        dp[i] = kvalid ? dp[i] : 0.f;
+                    }
+                }
+                bf16x8 pf[2], dsf[2];
+                pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+                pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+                dsf[0] = pack8(dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[7]);
+                dsf[1] = pack8(dp[8], dp[9], dp[10], dp[11], dp[12], dp[13], dp[14], dp[15]);
+                // dS^T image: row = key (wave*32 + r), 32 q per row (64 B); 32-B halves swapped when (key>>3)&1
+                {
+                    const int krow = wave * 32 + r;
+                    char* row = dsimg + krow * 64;
+                    const int hs = (krow >> 3) & 1;
+                    const uint2* d2 = reinterpret_cast<const uint2*>(dsf);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int q = 8 * g4 + 4 * h2;   // first of 4 consecutive query rows
+                        const int byte = ((((q >> 4) ^ hs) << 5) | ((q & 15) << 1));
+                        *reinterpret_cast<uint2*>(row + byte) = d2[g4];
+                    }
+                }
+                // dV^T[d][key] += dO^T[d][q].P[q][key] ; dK^T[d][key] += Q^T[d][q].dS[q][key]
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss) {
+                        const int qlo = 16 * ss + 4 * h2 + qq;
+                        const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
+                        const bf16x8 dot = join_tr_a(lds_tr16a(doimg + off128(qlo, col)),
+                                                     lds_tr16a(doimg + off128(qlo + 8, col)));
+                        const bf16x8 qt = join_tr_a(lds_tr16a(qimg + off128(qlo, col)),
+                                                    lds_tr16a(qimg + off128(qlo + 8, col)));
+                        dv[db] = MFMA32(dot, pf[ss], dv[db]);
+                        dk[db] = MFMA32(qt, dsf[ss], dk[db]);
+                    }
+            }
+            // one barrier per slice: the dS image is double buffered, so a wave that runs ahead into slice sl+1
+            // writes the other buffer, and cannot reach slice sl+2 before everyone has passed slice sl+1's barrier.
+            __syncthreads();
+            // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys ----
+            {
+                const int qh = wave & 1, dblk = wave >> 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks < nks) {
+                        const int klo = ks * 32 + 8 * gi + qq;
+                        const int khi = klo + 4;
+                        const int qcol = 4 * pp;   // within the 16-query half
+                        const int blo = klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | (qcol << 1));
+                        const int bhi = khi * 64 + ((((qh ^ ((khi >> 3) & 1)) << 5)) | (qcol << 1));
+                        const bf16x8 dst = join_tr_a(lds_tr16a(dsimg + blo), lds_tr16a(dsimg + bhi));
+                        acc = MFMA16(ktf[ks], dst, acc);   // D[d][q] = sum_key K[key][d] dS[q][key]
+                    }
+                }
+                const int q = qc + sl * 32 + qh * 16 + (lane & 15);
+                const int d0 = dblk * 16 + (lane >> 4) * 4;
+                if (q < T) {
+                    if (p.dq_acc == nullptr) {
+                        *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
+                            pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+                    } else {
+                        float* dst = p.dq_acc + (((size_t)b * T + q) * H + h) * HD + d0;
+                        atomicAdd(dst, acc[0] * p.scale); atomicAdd(dst + 1, acc[1] * p.scale);
+                        atomicAdd(dst + 2, acc[2] * p.scale); atomicAdd(dst + 3, acc[3] * p.scale);
+                    }
                 }
             }
+            dsbuf ^= 1;
         }
-        __syncthreads();
-        // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys ----
-        {
-            const int qh = wave & 1, dblk = wave >> 1;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int nks = min(8, (T - key_base + 31) >> 5);
-            for (int ks = 0; ks < nks; ++ks) {
-                const int klo = ks * 32 + 8 * gi + qq;
-                const int khi = klo + 4;
-                const int kcol = dblk * 16 + 4 * pp;
-                const bf16x8 kt = join_tr_a(lds_tr16a(smem + BW_KIMG + off128(klo, kcol)),
-                                            lds_tr16a(smem + BW_KIMG + off128(khi, kcol)));
-                const int qcol = 4 * pp;   // within the 16-query half
-                const int blo = klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | (qcol << 1));
-                const int bhi = khi * 64 + ((((qh ^ ((khi >> 3) & 1)) << 5)) | (qcol << 1));
-                const bf16x8 dst = join_tr_a(lds_tr16a(smem + BW_DS + blo), lds_tr16a(smem + BW_DS + bhi));
-                acc = MFMA16(kt, dst, acc);   // D[d][q] = sum_key K[key][d] dS[q][key]
-            }
-            const int q = sl * 32 + qh * 16 + (lane & 15);
-            const int d0 = dblk * 16 + (lane >> 4) * 4;
-            if (q < T) {
-                if (p.dq_acc == nullptr) {
-                    *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
-                        pack4bf(acc[0], acc[1], acc[2], acc[3]);
-                } else {
-                    float* dst = p.dq_acc + (((size_t)b * T + q) * H + h) * HD + d0;
-                    atomicAdd(dst, acc[0]); atomicAdd(dst + 1, acc[1]);
-                    atomicAdd(dst + 2, acc[2]); atomicAdd(dst + 3, acc[3]);
-                }
-            }
-        }
-        // the next iteration's first barrier (after its S/dP phase) orders the dS image reuse: writes of
-        // iteration sl+1 happen only after every wave has left this dQ phase?  No -- waves are free to run
-        // ahead, so fence here.
-        __syncthreads();
     }
 
     if (mykey < T) {
@@ -407,7 +428,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = db * 32 + 8 * g4 + 4 * h2;
                 *reinterpret_cast<uint2*>(krow + d0) =
-                    pack4bf(dk[db][4 * g4], dk[db][4 * g4 + 1], dk[db][4 * g4 + 2], dk[db][4 * g4 + 3]);
+                    pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale, dk[db][4 * g4 + 2] * p.scale,
+                            dk[db][4 * g4 + 3] * p.scale);
                 *reinterpret_cast<uint2*>(vrow + d0) =
                     pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
             }
@@ -439,10 +461,7 @@ int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T
 }
 
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
-    size_t n = (size_t)B * H * T * sizeof(float);                       // delta
-    n = (n + 255) & ~(size_t)255;
-    if (T > 256) n += (size_t)B * T * H * HD * sizeof(float);           // dq_acc
-    return n;
+    return T > 256 ? (size_t)B * T * H * HD * sizeof(float) : 0;        // dq_acc (fp32 atomics across key blocks)
 }
 
 int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
@@ -450,24 +469,15 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_attn_bwd_workspace_bytes(B, T, H), "attn_bwd: workspace too small");
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
-                        ((uintptr_t)out % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
+                        ((uintptr_t)out % 16 == 0) && (T <= 256 || (uintptr_t)workspace % 256 == 0),
                     "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
-    float* delta = reinterpret_cast<float*>(workspace);
     float* dq_acc = nullptr;
     if (T > 256) {
-        size_t off = ((size_t)B * H * T * sizeof(float) + 255) & ~(size_t)255;
-        dq_acc = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + off);
+        dq_acc = reinterpret_cast<float*>(workspace);
         if (hipMemsetAsync(dq_acc, 0, (size_t)B * T * H * HD * sizeof(float), st) != hipSuccess) {
             getmi_set_error("attn_bwd: memset failed");
             return GETMI_ERR_LAUNCH;
         }
-    }
-    {
-        const size_t n = (size_t)B * T * H;
-        int grid = (int)((n + 255) / 256);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3(grid), dim3(256), 0, st, out, dout, delta, B, T, H);
-        GETMI_CHECK_LAUNCH("attn_delta");
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -475,7 +485,7 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS);
         attr_set = true;
     }
-    AttnBwdArgs a{qkv, dout, lse, delta, dqkv, dq_acc, B, T, H, scale};
+    AttnBwdArgs a{qkv, out, dout, lse, dqkv, dq_acc, B, T, H, scale};
     const int nkb = (T + 255) / 256;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");
