@@ -86,6 +86,8 @@ class GradBuckets:
                 p.grad = None
         self._remaining = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._stray = [[] for _ in self.buckets]
+        self._cb_queued = False
         self._handles = []
 
     def _launch(self, bi):
@@ -101,13 +103,31 @@ class GradBuckets:
     def _on_grad(self, p):
         view = self._view[p]
         g = p.grad
-        if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
-            view.copy_(g)          # small parameters (biases, norms, tokens) and anything not written in place
-            p.grad = view
         bi = self._bucket_of[p]
+        if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
+            # small parameters (biases, norms, tokens) and anything not written in place: gathered into the
+            # bucket by ONE multi-tensor copy when the bucket completes, instead of a copy launch per parameter
+            self._stray[bi].append((view, g))
+            p.grad = view
+            if not self._cb_queued:      # buckets that stay incomplete (unused parameters) are flushed when this
+                self._cb_queued = True   # backward pass ends, so a following accumulate-backward sees real data
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         self._remaining[bi] -= 1
-        if self._remaining[bi] == 0 and self.sync:
-            self._launch(bi)
+        if self._remaining[bi] == 0:
+            self._flush(bi)
+            if self.sync:
+                self._launch(bi)
+
+    def _end_of_backward(self):
+        self._cb_queued = False
+        for bi in range(len(self.buckets)):
+            self._flush(bi)
+
+    def _flush(self, bi):
+        stray = self._stray[bi]
+        if stray:
+            torch._foreach_copy_([v for v, _ in stray], [g for _, g in stray])
+            self._stray[bi] = []
 
     def finish(self):
         """Call after backward: zero-fills the slots of parameters that got no gradient (unused), launches the
@@ -119,6 +139,7 @@ class GradBuckets:
                     view.zero_()
                     p.grad = view
         for bi in range(len(self.buckets)):
+            self._flush(bi)
             if not self._launched[bi]:
                 self._launch(bi)
         for h, flat in self._handles:
