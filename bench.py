@@ -37,6 +37,35 @@ def synthetic_batch(B, N, seed, device):
     return {"region_motif": rm.to(device), "exp_label": exp.to(device)}
 
 
+# bench kernel group -> (primary device kernels, helper kernels launched with them), as rocprofv3 names them
+_TRAFFIC_GROUPS = {
+    "gemm_wgrad_kernel(+reduce_slabs)": (["gemm_wgrad256_kernel", "gemm_wgrad_kernel"], ["reduce_slabs_kernel"]),
+    "gemm_tn_kernel<bf16>": (["gemm_tn256p_kernel<0>", "gemm_tn256_kernel<0>", "gemm_tn_kernel<0>"], []),
+    "gemm_tn_kernel<bias_gelu>": (["gemm_tn256p_kernel<1>", "gemm_tn256_kernel<1>", "gemm_tn_kernel<1>"], []),
+    "gemm_tn_kernel<bias_resid>": (["gemm_tn256p_kernel<2>", "gemm_tn256_kernel<2>", "gemm_tn_kernel<2>"], []),
+    "gemm_tn_kernel<dgelu>": (["gemm_tn256p_kernel<3>", "gemm_tn256_kernel<3>", "gemm_tn_kernel<3>"], []),
+    "attn_bwd_kernel(+delta)": (["attn_bwd_kernel"], []),
+    "attn_fwd_kernel": (["attn_fwd_kernel"], []),
+}
+
+
+def pmc_traffic(group):
+    """HBM-side bytes per launch of a kernel group (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md corrections),
+    from the committed rocprofv3 --pmc passes of this same workload (tools/pmc_traffic.sh -> profiles/); PMC
+    counters cannot be read from inside the process, so this is None when the file or the group is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if group not in _TRAFFIC_GROUPS or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    prim, helpers = _TRAFFIC_GROUPS[group]
+    calls = sum(d[k]["calls"] for k in prim if k in d)
+    if calls == 0:
+        return None
+    tot = sum(d[k]["calls"] * (d[k]["fetch_bytes"] + d[k]["write_bytes"]) for k in prim + helpers if k in d)
+    return tot / calls
+
+
 def cpu_baseline(budget_s=20.0):
     """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores:
     BASELINE.json configs[0] shape (B=4, N=200, 12 layers), train-mode-equivalent fwd + loss + bwd."""
@@ -151,7 +180,8 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             fl, sec, n = agg[dom]
             roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
+                    "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                     "launches": n, "avg_launch_us": sec / n * 1e6}
         result = {
             "metric": "train regions/sec/node, GET 12Lx768 @200-region ctx", "value": value, "unit": "regions/s",
