@@ -49,30 +49,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf-GELU and its derivative, fp32.  Phi(x) = 0.5*(1 + erf(x/sqrt2)) as 0.5 + x*P(x^2) on x clamped to [-4.5, 4.5]
-// (degree-9 minimax fit, |error| <= 1.3e-5 evaluated in fp32 -- 1/300 of the bf16 rounding of the stored result;
-// tests/test_kernels_gpu.py pins it against torch's erf form).  Pure FMA: the GELU / dGELU GEMM epilogues are
-// VALU-issue bound in lock-step waves, and the previous Abramowitz-Stegun 7.1.26 form (v_rcp + v_exp + 14 ops per
-// element) cost ~40 us of a 330-us fc1 GEMM; this one is 12 full-rate ops (+ one v_exp for the derivative's pdf).
-__device__ __forceinline__ float norm_cdf(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -4.5f, 4.5f);
-    const float t = xc * xc;
-    float p = -1.726324812e-12f;
-    p = fmaf(p, t, 2.022436246e-10f);
-    p = fmaf(p, t, -1.056708765e-08f);
-    p = fmaf(p, t, 3.278919962e-07f);
-    p = fmaf(p, t, -6.813724667e-06f);
-    p = fmaf(p, t, 1.017340546e-04f);
-    p = fmaf(p, t, -1.142715104e-03f);
-    p = fmaf(p, t, 9.891773574e-03f);
-    p = fmaf(p, t, -6.642068177e-02f);
-    p = fmaf(p, t, 3.989246786e-01f);
-    return fmaf(xc, p, 0.5f);
+// exact (erf) GELU and its derivative, fp32.  Phi(x) = 0.5*erfc(-x/sqrt2) through Abramowitz-Stegun 7.1.26
+// (|abs error of erf| <= 1.5e-7, far below the bf16 rounding of the stored result): one v_rcp + one v_exp.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& pdf) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float tail = 0.5f * poly * t * e;          // 0.5*erfc(|x|/sqrt2)
+    Phi = x >= 0.f ? 1.0f - tail : tail;
+    pdf = 0.3989422804014327f * e;
 }
-__device__ __forceinline__ float gelu_f(float x) { return x * norm_cdf(x); }
+__device__ __forceinline__ float gelu_f(float x) {
+    float Phi, pdf;
+    gelu_parts(x, Phi, pdf);
+    return x * Phi;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // N(0,1) density
-    return fmaf(x, pdf, norm_cdf(x));
+    float Phi, pdf;
+    gelu_parts(x, Phi, pdf);
+    return fmaf(x, pdf, Phi);
 }
 
 // ---- transposed LDS reads (ds_read_b64_tr_b16) in inline asm ------------------------------------------------
