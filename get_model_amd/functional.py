@@ -35,13 +35,14 @@ class _WeightCache:
 
     def __init__(self):
         self._c = {}
+        self.epoch = 0      # bumped after every optimizer step (see _after_optimizer_step)
 
     def get(self, w, kind, make):
         if not isinstance(w, torch.nn.Parameter):
             return make(w)          # e.g. a LoRA-parametrised weight: new tensor every access
         key = (id(w), kind)
         hit = self._c.get(key)
-        tag = (w._version, w.data_ptr(), tuple(w.shape))
+        tag = (w._version, w.data_ptr(), tuple(w.shape), self.epoch)
         # id() and data_ptr() are both recycled once a model is freed: the entry also pins the identity of the
         # parameter it was made from (weak reference, dropped together with the parameter).
         if hit is not None and hit[0] == tag and hit[2]() is w:
@@ -55,6 +56,19 @@ class _WeightCache:
 
 
 WEIGHTS = _WeightCache()
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    # Fused / foreach optimizers (torch.optim.AdamW(fused=True), apex, ...) update parameters without bumping
+    # `_version`, so the version tag alone would keep serving stale bf16 copies: every optimizer step of any
+    # optimizer in the process starts a new cache epoch.  Code that writes `param.data` by hand must call
+    # WEIGHTS.clear() itself.
+    WEIGHTS.epoch += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook  # noqa: E402
+
+register_optimizer_step_post_hook(_after_optimizer_step)
 
 
 def w_bf16(w):

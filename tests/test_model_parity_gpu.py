@@ -137,3 +137,36 @@ def test_grad_buckets_hold_the_same_gradients_without_copies():
     buckets.finish()
     for n, p in model.named_parameters():
         torch.testing.assert_close(p.grad, 2 * ref[n], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_optimizer_step_refreshes_the_bf16_weight_copies(fused):
+    """After optimizer.step() (fused AdamW does not bump Parameter._version) the next forward must use the new
+    weights: it has to equal, bit for bit, the forward of a fresh model loaded from the updated state_dict."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd.config import build_model, region_model_yaml
+    c = load_case("ft_L2_B2_N200_eval")
+    model = build_model(region_model_yaml("finetune", num_layers=2))
+    model.load_state_dict(c["sd"])
+    model = model.cuda().eval()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=fused)
+    batch = {k: v.cuda() for k, v in c["batch"].items()}
+
+    def loss_of(m):
+        out = m(**m.get_input(batch))
+        pred, obs = m.before_loss(out, batch)
+        return m.after_loss(m.loss(pred, obs))
+
+    l0 = loss_of(model)
+    l0.backward()
+    opt.step()
+    with torch.no_grad():
+        l1 = loss_of(model)
+    fresh = build_model(region_model_yaml("finetune", num_layers=2))
+    fresh.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        l2 = loss_of(fresh)
+    assert l1.item() != l0.item()
+    assert torch.equal(l1, l2), (l0.item(), l1.item(), l2.item())
