@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of FusedAdamW")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -119,13 +120,17 @@ def main():
     broadcast_parameters(model)
     model.train()
     buckets = GradBuckets(model)
-    # AdamW as the reference configures it (config/finetune_tutorial.yaml:29-35, optim.py:44-85)
-    no_decay = model.no_weight_decay()
-    decay, nodecay = [], []
-    for n, p in model.named_parameters():
-        (nodecay if (p.ndim <= 1 or n.endswith(".bias") or n in no_decay) else decay).append(p)
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": nodecay, "weight_decay": 0.0}],
-                            lr=1e-4, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    # AdamW as the reference configures it (config/finetune_tutorial.yaml:29-35, optim.py:44-130, run.py:477-497):
+    # layer-wise parameter groups, weight decay 0.05 on >=2-D non-bias parameters; get_model_amd.optim.FusedAdamW
+    # (one HIP launch, also refreshes the bf16 operand copies); --torch-adamw times torch.optim.AdamW(fused) instead
+    from types import SimpleNamespace
+    from get_model_amd import optim as GO
+    ocfg = SimpleNamespace(opt="adamw", lr=1e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+    if args.torch_adamw:
+        opt = torch.optim.AdamW(GO.get_parameter_groups(model, 0.05, model.no_weight_decay()), lr=1e-4,
+                                betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, fused=True)
+    else:
+        opt = GO.configure_optimizer(model, ocfg)
     B, N = args.batch, args.regions
     batch = synthetic_batch(B, N, 1234 + rank, device)
 

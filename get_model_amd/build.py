@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgetmi355.so")
-SOURCES = ["error.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "capi.hip"]
+SOURCES = ["error.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=fast"]
 
 

@@ -44,6 +44,9 @@ int getmi_colsum_bf16_impl(const bf16_t*, float*, int, int, int, int, void*, siz
 size_t getmi_scale_cast_workspace_bytes_impl(int M, int D);
 int getmi_scale_cast_impl(const float*, const float*, int, bf16_t*, float*, int, int, int, void*, size_t, hipStream_t);
 
+struct AdamGroup { float lr, weight_decay, beta1, beta2, eps, step_size, inv_sqrt_bc2, pad; };
+int getmi_adamw_step_impl(const void* jobs, int nflat, int ntile, const AdamGroup* groups, int ngroups, hipStream_t st);
+
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 #define BF(p) reinterpret_cast<const bf16_t*>(p)
 #define BFW(p) reinterpret_cast<bf16_t*>(p)
@@ -159,4 +162,10 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
                                  workspace_bytes, ST(stream));
 }
 
+int getmi_adamw_step(const void* jobs, int n_flat_jobs, int n_tile_jobs, const getmi_adamw_group* groups, int n_groups,
+                     void* stream) {
+    static_assert(sizeof(getmi_adamw_group) == sizeof(AdamGroup), "group layout");
+    return getmi_adamw_step_impl(jobs, n_flat_jobs, n_tile_jobs, reinterpret_cast<const AdamGroup*>(groups), n_groups,
+                                 ST(stream));
+}
 }  // extern "C"

@@ -51,6 +51,20 @@ class _WeightCache:
         self._c[key] = (tag, val, weakref.ref(w, lambda _r, k=key, c=self._c: c.pop(k, None) if (k in c and c[k][2]() is None) else None))
         return val
 
+    def peek(self, w, kind):
+        """The cached copy of `w` if it is current, else None (never creates one)."""
+        hit = self._c.get((id(w), kind))
+        if hit is None or hit[2]() is not w or hit[0][:3] != (w._version, w.data_ptr(), tuple(w.shape)) or \
+                hit[0][3] < self.epoch - 1:
+            return None
+        return hit[1]
+
+    def retag(self, w, kind):
+        """Declare the cached copy current again (its storage was rewritten in place, e.g. by optim.FusedAdamW)."""
+        key = (id(w), kind)
+        hit = self._c[key]
+        self._c[key] = ((w._version, w.data_ptr(), tuple(w.shape), self.epoch), hit[1], hit[2])
+
     def clear(self):
         self._c.clear()
 
@@ -63,7 +77,8 @@ def _after_optimizer_step(optimizer, args, kwargs):
     # `_version`, so the version tag alone would keep serving stale bf16 copies: every optimizer step of any
     # optimizer in the process starts a new cache epoch.  Code that writes `param.data` by hand must call
     # WEIGHTS.clear() itself.
-    WEIGHTS.epoch += 1
+    if not getattr(optimizer, "getmi_refreshes_weight_cache", False):   # optim.FusedAdamW maintains the copies itself
+        WEIGHTS.epoch += 1
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook  # noqa: E402

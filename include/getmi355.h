@@ -114,6 +114,20 @@ size_t getmi_colsum_workspace_bytes(int N);
 int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ---- fused multi-tensor AdamW: replaces torch.optim.AdamW as the reference configures it
+ *      (get_model/optim.py:96-130, config/finetune_tutorial.yaml:29-35) plus the per-forward weight casts of
+ *      autocast.  `jobs` is a DEVICE table of n_flat_jobs + n_tile_jobs records of 8 x int64
+ *      {p, g, m, v, w_bf16 [rows,cols] or 0, w_bf16_t [cols,rows] or 0, a, b}:
+ *        flat job: a = first element, b = count (<= 4096) | group << 40
+ *        tile job (64 x 64 tile of a 2-D weight, rows % 64 == cols % 64 == 0): a = r0 | c0 << 32,
+ *                  b = cols | rows << 20 | group << 40
+ *      `groups` is a HOST array (<= 64): step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t). */
+typedef struct {
+    float lr, weight_decay, beta1, beta2, eps, step_size, inv_sqrt_bc2, reserved;
+} getmi_adamw_group;
+int getmi_adamw_step(const void* jobs, int n_flat_jobs, int n_tile_jobs, const getmi_adamw_group* groups, int n_groups,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif
