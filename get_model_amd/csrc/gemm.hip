@@ -729,18 +729,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     GP_ISSUE(0, 0); GP_ISSUE(0, 1); GP_ISSUE(0, 2); GP_ISSUE(0, 3);
     GP_ISSUE(1, 0); GP_ISSUE(1, 1); GP_ISSUE(1, 2);              // Gk >= 2
 
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-#define GP_LOAD_A(MH)                                                                                      \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
-        fa[mt][ks] = *reinterpret_cast<const bf16x8*>(buf + a_base + ((MH)*64 + mt * 16) * 128 + foff[ks]);
-#define GP_LOAD_B(FB, NH)                                                                                  \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
-        FB[nt][ks] = *reinterpret_cast<const bf16x8*>(buf + b_base + ((NH)*32 + nt * 16) * 128 + foff[ks]);
-#define GP_MMA(MH, NH, FB)                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)      \
-        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
-            acc[(MH)*4 + mt][(NH)*2 + nt] =                                                                \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt][ks], fa[mt][ks], acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
+    // Fragment reads are inline asm with COUNTED lgkmcnt waits: hipcc clusters the ds_reads of a phase and puts one
+    // `s_waitcnt lgkmcnt(0)` in front of the first MFMA, which serialises the phase (all eight waves read LDS, then
+    // all compute: measured 55 % MFMA-busy in the loop = 2048 MFMA cycles / (2048 + 1536 LDS cycles) per K-tile).
+    // Reads are issued k-step-major (B pair, then the four A row-blocks), and every pair of MFMAs waits only for
+    // the fragments it consumes, so the MFMAs start after 3 of 12 reads and run under the rest.
+    // (form (ii) of cdna_hip_programming.md 5.7: a read's destination is undefined until the wait that names it.)
+    u32x4 fa[4][2], fb0[2][2], fb1[2][2];
+    const unsigned lds0 = lds_addr(smem);
+    unsigned la[2], lb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { la[ks] = lds0 + a_base + foff[ks]; lb[ks] = lds0 + b_base + foff[ks]; }
+#define GP_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define GP_LG1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x) : : "memory")
+#define GP_LG2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y) : : "memory")
+#define GP_LG3(N, x, y, z) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y), "+v"(z) : : "memory")
+#define GP_RD_A(MH, ks, addr)                                                                              \
+    GP_RD(fa[0][ks], addr, (MH)*8192); GP_RD(fa[1][ks], addr, (MH)*8192 + 2048);                           \
+    GP_RD(fa[2][ks], addr, (MH)*8192 + 4096); GP_RD(fa[3][ks], addr, (MH)*8192 + 6144);
+#define GP_RD_B(FB, NH, ks, addr) GP_RD(FB[0][ks], addr, (NH)*4096); GP_RD(FB[1][ks], addr, (NH)*4096 + 2048);
+    // the two MFMAs of row-block mt, k-step ks of quadrant (MH, NH)
+#define GP_MM(MH, NH, FB, mt, ks)                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
+        acc[(MH)*4 + mt][(NH)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
+            __builtin_bit_cast(bf16x8, FB[nt][ks]), __builtin_bit_cast(bf16x8, fa[mt][ks]),               \
+            acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);                                                       \
+    __builtin_amdgcn_sched_barrier(0);   /* keep the pair between its wait and the next one */
+#define GP_MM4(MH, NH, FB, ks) GP_MM(MH, NH, FB, 0, ks) GP_MM(MH, NH, FB, 1, ks) GP_MM(MH, NH, FB, 2, ks) GP_MM(MH, NH, FB, 3, ks)
     // counted wait of a reading phase: `win` > 0 while the needed half-tile predates the last epilogue
 #define GP_WAIT(inflight)                                                                                  \
     do {                                                                                                   \
@@ -750,30 +765,45 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
 
     int win = 0;
     for (int g = 0; g < Gk; ++g) {
-        const char* buf = smem + ((g & 1) << 16);
+        const unsigned bo = (unsigned)(g & 1) << 16;
+        const unsigned a0 = la[0] + bo, a1 = la[1] + bo, b0 = lb[0] + bo, b1 = lb[1] + bo;
         const int phi = g << 2;
-        // ---- P1 ----
+        // ---- P1: A-half0 x B-half0 (12 reads) ----
         GP_WAIT(min(phi + 6, Q - 1) - (phi + 1));
         phase_barrier();
-        GP_LOAD_A(0)
-        GP_LOAD_B(fb0, 0)
         if (g + 1 < Gk) GP_ISSUE(g + 1, 3);
-        GP_MMA(0, 0, fb0)
-        // ---- P2 ----
+        GP_RD_B(fb0, 0, 0, b0) GP_RD_A(0, 0, a0) GP_RD_B(fb0, 0, 1, b1) GP_RD_A(0, 1, a1)
+        GP_LG3(9, fb0[0][0], fb0[1][0], fa[0][0]); GP_MM(0, 0, fb0, 0, 0)
+        GP_LG1(8, fa[1][0]); GP_MM(0, 0, fb0, 1, 0)
+        GP_LG1(7, fa[2][0]); GP_MM(0, 0, fb0, 2, 0)
+        GP_LG1(6, fa[3][0]); GP_MM(0, 0, fb0, 3, 0)
+        GP_LG3(3, fb0[0][1], fb0[1][1], fa[0][1]); GP_MM(0, 0, fb0, 0, 1)
+        GP_LG1(2, fa[1][1]); GP_MM(0, 0, fb0, 1, 1)
+        GP_LG1(1, fa[2][1]); GP_MM(0, 0, fb0, 2, 1)
+        GP_LG1(0, fa[3][1]); GP_MM(0, 0, fb0, 3, 1)
+        // ---- P2: A-half0 (in registers) x B-half1 (4 reads) ----
         GP_WAIT(min(phi + 7, Q - 1) - (phi + 2));
         phase_barrier();
-        GP_LOAD_B(fb1, 1)
         if (g + 2 < Gk) GP_ISSUE(g + 2, 0);
-        GP_MMA(0, 1, fb1)
-        // ---- P3 ----
+        GP_RD_B(fb1, 1, 0, b0) GP_RD_B(fb1, 1, 1, b1)
+        GP_LG2(2, fb1[0][0], fb1[1][0]); GP_MM4(0, 1, fb1, 0)
+        GP_LG2(0, fb1[0][1], fb1[1][1]); GP_MM4(0, 1, fb1, 1)
+        // ---- P3: A-half1 (8 reads) x B-half1 (in registers) ----
         GP_WAIT(min(phi + 8, Q - 1) - (phi + 3));
         phase_barrier();
-        GP_LOAD_A(1)
         if (g + 2 < Gk) GP_ISSUE(g + 2, 1);
-        GP_MMA(1, 1, fb1)
-        // ---- P4 ----
+        GP_RD_A(1, 0, a0) GP_RD_A(1, 1, a1)
+        GP_LG1(7, fa[0][0]); GP_MM(1, 1, fb1, 0, 0)
+        GP_LG1(6, fa[1][0]); GP_MM(1, 1, fb1, 1, 0)
+        GP_LG1(5, fa[2][0]); GP_MM(1, 1, fb1, 2, 0)
+        GP_LG1(4, fa[3][0]); GP_MM(1, 1, fb1, 3, 0)
+        GP_LG1(3, fa[0][1]); GP_MM(1, 1, fb1, 0, 1)
+        GP_LG1(2, fa[1][1]); GP_MM(1, 1, fb1, 1, 1)
+        GP_LG1(1, fa[2][1]); GP_MM(1, 1, fb1, 2, 1)
+        GP_LG1(0, fa[3][1]); GP_MM(1, 1, fb1, 3, 1)
+        // ---- P4: A-half1 x B-half0, both in registers (no barrier) ----
         if (g + 2 < Gk) GP_ISSUE(g + 2, 2);
-        GP_MMA(1, 0, fb0)
+        GP_MM4(1, 0, fb0, 0) GP_MM4(1, 0, fb0, 1)
 
         if (g - tile_g0 == nk - 1) {
             // ---- tile finished: epilogue (its stores drain under the next tile), then switch tiles ----
@@ -795,9 +825,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
         }
     }
 #undef GP_ISSUE
-#undef GP_LOAD_A
-#undef GP_LOAD_B
-#undef GP_MMA
+#undef GP_RD
+#undef GP_LG1
+#undef GP_LG2
+#undef GP_LG3
+#undef GP_RD_A
+#undef GP_RD_B
+#undef GP_MM
+#undef GP_MM4
 #undef GP_WAIT
 }
 
