@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of FusedAdamW")
+    ap.add_argument("--inference", action="store_true",
+                    help="forward only, eval mode, torch.inference_mode (SURVEY 8d C5); not the contract metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -118,7 +120,7 @@ def main():
     torch.manual_seed(0)
     model = build_model(region_model_yaml("finetune", num_layers=args.layers)).to(device)
     broadcast_parameters(model)
-    model.train()
+    model.train(not args.inference)
     buckets = GradBuckets(model)
     # AdamW as the reference configures it (config/finetune_tutorial.yaml:29-35, optim.py:44-130, run.py:477-497):
     # layer-wise parameter groups, weight decay 0.05 on >=2-D non-bias parameters; get_model_amd.optim.FusedAdamW
@@ -134,7 +136,13 @@ def main():
     B, N = args.batch, args.regions
     batch = synthetic_batch(B, N, 1234 + rank, device)
 
+    def infer_step():
+        with torch.inference_mode():
+            return model(**model.get_input(batch)).float().mean()
+
     def step():
+        if args.inference:
+            return infer_step()
         buckets.zero_grad()
         out = model(**model.get_input(batch))
         pred, obs = model.before_loss(out, batch)
@@ -189,7 +197,8 @@ def main():
                     "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                     "launches": n, "avg_launch_us": sec / n * 1e6}
         result = {
-            "metric": "train regions/sec/node, GET 12Lx768 @200-region ctx", "value": value, "unit": "regions/s",
+            "metric": ("inference" if args.inference else "train") + f" regions/sec/node, GET 12Lx768 @{N}-region ctx",
+            "value": value, "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic region x motif tensors (SURVEY.md 8d), random-init weights",

@@ -13,8 +13,8 @@
 //            accumulators for the whole sweep over 32-row query slices).  "Key on the lane": S = Q.K^T and
 //            dP = dO.V^T accumulators are the B operands of dV^T += dO^T.P and dK^T += Q^T.dS; only dS
 //            crosses LDS (transposed image) for dQ = dS.K, which the 8 waves compute as eight 16x16 tiles
-//            over all 256 keys -> no cross-wave or cross-workgroup reduction when T <= 256 (fp32 atomics
-//            into dq_acc otherwise).
+//            over all 256 keys -> no cross-wave or cross-workgroup reduction when T <= 256 (per-key-block fp32
+//            slabs summed by a small kernel otherwise).
 #include "common.h"
 
 #define HD 64
@@ -193,7 +193,7 @@ struct AttnBwdArgs {
     const bf16_t* dout;   // [B,T,H*64]
     const float* lse;     // [B,H,T]
     bf16_t* dqkv;         // [B,T,3,H,64]
-    float* dq_acc;        // [B,T,H,64] fp32, only when T > 256
+    float* dq_acc;        // [nkb][B,T,H,64] fp32 partial dQ per 256-key block, only when T > 256
     int B, T, H;
     float scale;
 };
@@ -409,9 +409,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                         *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
                             pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
                     } else {
-                        float* dst = p.dq_acc + (((size_t)b * T + q) * H + h) * HD + d0;
-                        atomicAdd(dst, acc[0] * p.scale); atomicAdd(dst + 1, acc[1] * p.scale);
-                        atomicAdd(dst + 2, acc[2] * p.scale); atomicAdd(dst + 3, acc[3] * p.scale);
+                        // long context: this key block's partial dQ goes to its own fp32 slab (plain 16-byte
+                        // stores; fp32 atomics measured 2.5 ms per call at T = 2001), summed by attn_dq_convert
+                        float* dst = p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * (H * HD) + h * HD + d0;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0] * p.scale, acc[1] * p.scale,
+                                                                      acc[2] * p.scale, acc[3] * p.scale);
                     }
                 }
             }
@@ -436,14 +438,18 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     }
 }
 
-// dqkv[b,t,0,h,:] = bf16(dq_acc[b,t,h,:])   (long-context path only)
+// dqkv[b,t,0,h,:] = bf16(sum over key blocks of dq_acc[kb][b,t,h,:])   (long-context path only)
 __global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dqkv, size_t ntok,
-                                       int H) {
+                                       int H, int nkb) {
     const size_t n4 = ntok * H * (HD / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t tok = i / (H * (HD / 4));
         const int rem = (int)(i - tok * (H * (HD / 4)));
-        const float4 v = *reinterpret_cast<const float4*>(acc + i * 4);
+        float4 v = *reinterpret_cast<const float4*>(acc + i * 4);
+        for (int kb = 1; kb < nkb; ++kb) {
+            const float4 w = *reinterpret_cast<const float4*>(acc + ((size_t)kb * n4 + i) * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
         *reinterpret_cast<uint2*>(dqkv + tok * (size_t)(3 * H * HD) + rem * 4) = pack4bf(v.x, v.y, v.z, v.w);
     }
 }
@@ -461,7 +467,7 @@ int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T
 }
 
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
-    return T > 256 ? (size_t)B * T * H * HD * sizeof(float) : 0;        // dq_acc (fp32 atomics across key blocks)
+    return T > 256 ? (size_t)((T + 255) / 256) * B * T * H * HD * sizeof(float) : 0;   // per-key-block dQ slabs
 }
 
 int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
@@ -472,13 +478,7 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
                         ((uintptr_t)out % 16 == 0) && (T <= 256 || (uintptr_t)workspace % 256 == 0),
                     "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
     float* dq_acc = nullptr;
-    if (T > 256) {
-        dq_acc = reinterpret_cast<float*>(workspace);
-        if (hipMemsetAsync(dq_acc, 0, (size_t)B * T * H * HD * sizeof(float), st) != hipSuccess) {
-            getmi_set_error("attn_bwd: memset failed");
-            return GETMI_ERR_LAUNCH;
-        }
-    }
+    if (T > 256) dq_acc = reinterpret_cast<float*>(workspace);   // every slab element is written by its key block
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
@@ -493,7 +493,7 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
         const size_t n4 = (size_t)B * T * H * (HD / 4);
         int grid = (int)((n4 + 255) / 256);
         if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(attn_dq_convert_kernel, dim3(grid), dim3(256), 0, st, dq_acc, dqkv, (size_t)B * T, H);
+        hipLaunchKernelGGL(attn_dq_convert_kernel, dim3(grid), dim3(256), 0, st, dq_acc, dqkv, (size_t)B * T, H, nkb);
         GETMI_CHECK_LAUNCH("attn_dq_convert");
     }
     return GETMI_OK;

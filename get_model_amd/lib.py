@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgetmi355.so")
+LIB_PATH = os.environ.get("GETMI_LIB", os.path.join(_HERE, "libgetmi355.so"))   # GETMI_LIB: A/B another build
 
 _vp, _i, _i64, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
