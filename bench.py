@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of FusedAdamW")
+    ap.add_argument("--cu-limit", type=int, default=0, help="experiment: getmi_set_cu_limit before the run")
     ap.add_argument("--inference", action="store_true",
                     help="forward only, eval mode, torch.inference_mode (SURVEY 8d C5); not the contract metric")
     args = ap.parse_args()
@@ -157,6 +158,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.cu_limit:
+        from get_model_amd.ddp import set_cu_limit
+        set_cu_limit(args.cu_limit)
+    # (N > 1) pick the gradient-exchange mode by measurement; these steps come before the warm-up and are not timed
+    from get_model_amd.ddp import autotune
+    exchange = autotune(step, buckets) if (world > 1 and not args.inference) else None
     for _ in range(args.warmup):
         step()
     fence()
@@ -204,7 +211,7 @@ def main():
             "data": "synthetic region x motif tensors (SURVEY.md 8d), random-init weights",
             "config": {"workload": f"GETRegionFinetune {args.layers}Lx768 train step (fwd+PoissonNLL+bwd+grad all-reduce+AdamW), "
                                    f"per-GPU batch {B} x {N} regions x 283 features", "global_batch": world * B,
-                       "regions_per_sample": N, "parallelism": f"dp{world}"},
+                       "regions_per_sample": N, "parallelism": f"dp{world}", "grad_exchange": exchange},
             "loss": float(loss.item()),
             "e2e_mfma_frac": value * FLOP_PER_REGION_N200 / (world * PEAK_BF16_TFLOPS * 1e12) if N == 200 and args.layers == 12 else None,
             "roofline": roof, "kernels": kernels,

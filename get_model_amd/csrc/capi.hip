@@ -12,6 +12,8 @@ int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* 
                          hipStream_t st);
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st);
 int getmi_wgrad_nsplit(int M, int N1, int N2);
+int getmi_set_cu_limit_impl(int n);
+int getmi_cu_count_impl();
 int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N2, int ldx, int ldy, float* out,
                           int accumulate, float* slabs, size_t slab_bytes, hipStream_t st);
 int getmi_ln_fwd_impl(const float*, const float*, const float*, bf16_t*, float*, float*, int, int, float, hipStream_t);
@@ -161,6 +163,9 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
     return getmi_scale_cast_impl(dx, rowscale, rows_per_sample, BFW(dz), dbias, accumulate, M, D, workspace,
                                  workspace_bytes, ST(stream));
 }
+
+int getmi_set_cu_limit(int n) { return getmi_set_cu_limit_impl(n); }
+int getmi_cu_count(void) { return getmi_cu_count_impl(); }
 
 int getmi_adamw_step(const void* jobs, int n_flat_jobs, int n_tile_jobs, const getmi_adamw_group* groups, int n_groups,
                      void* stream) {

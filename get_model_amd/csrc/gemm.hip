@@ -1186,7 +1186,30 @@ static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
     return GETMI_OK;
 }
 
+// CUs the one-workgroup-per-CU kernels (persistent GEMM, wgrad) may assume they get.  These workgroups take a
+// whole CU (148 KiB LDS, all 512 VGPRs of every SIMD), so a CU that hosts any other resident wave -- e.g. one of
+// RCCL's channel workgroups while a gradient all-reduce overlaps backward -- cannot take one, and with a grid
+// equal to the CU count the displaced workgroups run as a SECOND round (2x kernel time).  getmi_set_cu_limit(n)
+// shrinks the grids to n so that cannot happen; ddp.autotune measures whether it pays.
 static int g_num_cu = 0;
+static int g_cu_limit = 0;
+static int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_num_cu = n;
+    }
+    return (g_cu_limit > 0 && g_cu_limit < g_num_cu) ? g_cu_limit : g_num_cu;
+}
+int getmi_set_cu_limit_impl(int n) {
+    const int prev = g_cu_limit;
+    g_cu_limit = n > 0 ? n : 0;
+    return prev;
+}
+int getmi_cu_count_impl() { return num_cu(); }
+
 template <int EPI>
 static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
@@ -1195,15 +1218,8 @@ static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS + 1024 + 16384);
         attr_set = true;
     }
-    if (g_num_cu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        g_num_cu = n;
-    }
     const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const int grid = ntiles < g_num_cu ? ntiles : g_num_cu;
+    const int grid = ntiles < num_cu() ? ntiles : num_cu();
     hipLaunchKernelGGL(gemm_tn256p_kernel<EPI>, dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles);
     GETMI_CHECK_LAUNCH("gemm_tn256p");
     return GETMI_OK;
@@ -1288,7 +1304,7 @@ int getmi_wgrad_nsplit(int M, int N1, int N2) {
     const int nk = (M + BK - 1) / BK;
     // one full wave of blocks (big tile: 1 block/CU -> 256 slots; 128x128: 2 blocks/CU -> 512 slots): never
     // spill a few blocks into a second round
-    int want = (big ? 256 : 512) / ntile;
+    int want = (big ? num_cu() : 2 * num_cu()) / ntile;
     if (want < 1) want = 1;
     if (want > nk) want = nk;
     if (want > 64) want = 64;

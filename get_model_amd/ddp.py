@@ -11,6 +11,8 @@ gradients.  Differences by design:
     gradients in place; the weight-gradient GEMMs write their result directly into the bucket slot
     (`param.getmi_grad_buffer`), which autograd then adopts as `param.grad` without a copy or an add;
   * no unused-parameter graph walk: parameters that received no gradient are simply reduced as zeros.
+  * how the exchange shares the GPU with backward is MEASURED per node (`autotune`): overlapped on all CUs,
+    overlapped with some CUs left to RCCL (the persistent GEMM / wgrad kernels take whole CUs), or not overlapped.
 Works with any backend (`gloo` on CPU for the tests).
 """
 import re
@@ -73,6 +75,7 @@ class GradBuckets:
                 p.grad = None
             self.flat.append(flat)
         self.sync = True      # False: accumulate locally (micro-batches); the exchange happens in finish()
+        self.overlap = True   # False: no all-reduce is launched during backward, all of them start in finish()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.zero_grad()
@@ -115,7 +118,7 @@ class GradBuckets:
         self._remaining[bi] -= 1
         if self._remaining[bi] == 0:
             self._flush(bi)
-            if self.sync:
+            if self.sync and self.overlap:
                 self._launch(bi)
 
     def _end_of_backward(self):
@@ -151,6 +154,64 @@ class GradBuckets:
     def remove(self):
         for h in self._hooks:
             h.remove()
+
+
+def set_cu_limit(n):
+    """Grid size the one-workgroup-per-CU kernels assume (include/getmi355.h: getmi_set_cu_limit); 0 = all CUs.
+    No-op without a GPU (the gloo tests)."""
+    if not torch.cuda.is_available():
+        return 0
+    from . import lib
+    return lib.query("getmi_set_cu_limit", int(n))
+
+
+def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
+    """Measure, on this node, how the gradient exchange should share the GPU with backward, and leave the winner set.
+
+    Candidates: all-reduces overlapped with backward on all CUs; overlapped with `r` CUs left to RCCL's channel
+    workgroups (the persistent GEMM / wgrad kernels take whole CUs and would otherwise run a second round for the
+    displaced workgroups); and no overlap (every all-reduce starts after backward).  Each candidate runs one
+    settling step and `steps` timed steps of `step_fn` (a full training step incl. buckets.finish()); ranks agree on
+    the maximum time.  Returns {"overlap": bool, "cu_limit": int, "ms": {candidate: ms_per_step}}.
+    world_size 1: nothing to tune."""
+    import time
+    result = {"overlap": True, "cu_limit": 0, "ms": {}}
+    if buckets.world == 1:
+        return result
+    gpu = torch.cuda.is_available()
+    total = 0
+    if gpu:
+        from . import lib
+        set_cu_limit(0)
+        total = lib.query("getmi_cu_count")
+    cands = [(True, 0)] + [(True, total - r) for r in reserve_options if gpu and total - r >= 64] + [(False, 0)]
+
+    def fence():
+        if gpu:
+            torch.cuda.synchronize()
+        dist.barrier(group=buckets.pg)
+
+    best = None
+    for overlap, limit in cands:
+        buckets.overlap = overlap
+        set_cu_limit(limit)
+        step_fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64,
+                         device=buckets.flat[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=buckets.pg)
+        ms = float(t.item())
+        result["ms"]["%s/%d" % ("overlap" if overlap else "serial", limit)] = ms
+        if best is None or ms < best[0]:
+            best = (ms, overlap, limit)
+    buckets.overlap = best[1]
+    set_cu_limit(best[2])
+    result["overlap"], result["cu_limit"] = best[1], best[2]
+    return result
 
 
 def broadcast_parameters(module, src=0, process_group=None):

@@ -114,6 +114,15 @@ size_t getmi_colsum_workspace_bytes(int N);
 int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ---- sharing the GPU with communication kernels.  No counterpart in the reference (its GEMMs come from vendor
+ *      libraries).  The persistent GEMM and the weight-gradient GEMM launch one workgroup per CU, each taking the
+ *      whole CU; while RCCL's channel workgroups are resident (gradient all-reduce overlapped with backward) some
+ *      CUs cannot host them and the displaced workgroups would run as a second round.  getmi_set_cu_limit(n) makes
+ *      those kernels size their grids for n CUs (0 = all CUs again) and returns the previous limit; process-wide,
+ *      takes effect at the next launch.  getmi_cu_count() = the CU count currently assumed. */
+int getmi_set_cu_limit(int n);
+int getmi_cu_count(void);
+
 /* ---- fused multi-tensor AdamW: replaces torch.optim.AdamW as the reference configures it
  *      (get_model/optim.py:96-130, config/finetune_tutorial.yaml:29-35) plus the per-forward weight casts of
  *      autocast.  `jobs` is a DEVICE table of n_flat_jobs + n_tile_jobs records of 8 x int64

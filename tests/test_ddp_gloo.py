@@ -47,6 +47,26 @@ def _worker(rank, world, port, out_path):
         ((m(xs) - ys) ** 2).mean().backward()
         gb.finish()
     grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    # exchange-mode autotune (overlapped vs serial; the CU-limit candidates need a GPU): both ranks must agree, and
+    # the gradients must be the same whichever mode wins and in the serial mode explicitly
+    from get_model_amd.ddp import autotune
+
+    def step_fn():
+        gb.zero_grad()
+        ((m(xs) - ys) ** 2).mean().backward()
+        gb.finish()
+
+    res = autotune(step_fn, gb, steps=1)
+    assert set(res["ms"]) == {"overlap/0", "serial/0"} and res["cu_limit"] == 0
+    agree = torch.tensor([1.0 if res["overlap"] else 0.0])
+    dist.all_reduce(agree)
+    assert agree.item() in (0.0, float(world))
+    for mode in (res["overlap"], False):
+        gb.overlap = mode
+        step_fn()
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, grads[n], atol=1e-7), (n, mode)
     if rank == 0:
         torch.save(({n: p.detach().clone() for n, p in m.named_parameters()}, grads, x, y), out_path)
     dist.barrier()

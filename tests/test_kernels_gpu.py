@@ -284,3 +284,30 @@ def test_errors_are_loud(K):
         K.layernorm_fwd(torch.zeros(4, 100, device="cuda"), torch.zeros(100, device="cuda"), torch.zeros(100, device="cuda"))
     with pytest.raises(RuntimeError, match="GPU"):
         K.cast_pad(torch.zeros(4, 8))
+
+
+def test_cu_limit_shrinks_grids_without_changing_results(K):
+    """getmi_set_cu_limit: the persistent GEMM and the weight-gradient GEMM size their grids for fewer CUs (used
+    when RCCL's workgroups share the GPU); same results (wgrad up to the fp32 summation order of its M-split)."""
+    from get_model_amd import lib
+    M, N, Kd = 4096 + 200, 768, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().cuda()
+    W = (torch.randn(N, Kd, generator=g) * 0.5).bfloat16().cuda()
+    Y = (torch.randn(M, N, generator=g) * 0.5).bfloat16().cuda()
+    total = lib.query("getmi_cu_count")
+    try:
+        out0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        K.gemm_tn(K.EPI_BF16, A, W, out0)
+        w0 = K.gemm_wgrad(Y, A)
+        assert lib.query("getmi_set_cu_limit", total - 56) == 0
+        assert lib.query("getmi_cu_count") == total - 56
+        out1 = torch.empty_like(out0)
+        K.gemm_tn(K.EPI_BF16, A, W, out1)
+        w1 = K.gemm_wgrad(Y, A)
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out1)
+        torch.testing.assert_close(w1, w0, rtol=1e-4, atol=1e-3)
+    finally:
+        lib.query("getmi_set_cu_limit", 0)
+    assert lib.query("getmi_cu_count") == total
