@@ -103,16 +103,26 @@ def main():
                     help="forward only, eval mode, torch.inference_mode (SURVEY 8d C5); not the contract metric")
     args = ap.parse_args()
 
+    if os.environ.get("GETMI_BENCH_TRACE"):          # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GETMI_BENCH_TRACE"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    # one rank per GPU; GETMI_BENCH_BACKEND=gloo lets several ranks share the GPUs of a smaller box (rehearsal of the
+    # multi-rank code path only -- its numbers mean nothing)
+    backend = os.environ.get("GETMI_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from get_model_amd import kernels as K
     from get_model_amd.config import build_model, region_model_yaml
@@ -176,7 +186,7 @@ def main():
     dt = time.perf_counter() - t0
     prof, K.PROFILE = K.PROFILE, None
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     ms = dt / args.steps * 1e3

@@ -100,6 +100,12 @@ class GradBuckets:
         flat = self.flat[bi]
         if self._use_avg:
             self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+        elif flat.is_cuda:
+            # a host backend (gloo) with GPU gradients: staged through host memory, synchronously (rehearsals of the
+            # multi-rank path on a box without RCCL peers; gloo's own CUDA path hangs on this stack)
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg)
+            flat.copy_(host.div_(self.world))
         else:
             self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat))
 
@@ -202,7 +208,7 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
             step_fn()
         fence()
         t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64,
-                         device=buckets.flat[0].device)
+                         device=buckets.flat[0].device if buckets._use_avg else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=buckets.pg)
         ms = float(t.item())
         result["ms"]["%s/%d" % ("overlap" if overlap else "serial", limit)] = ms
@@ -218,6 +224,12 @@ def broadcast_parameters(module, src=0, process_group=None):
     """Make every rank start from rank `src`'s weights (what DDP does at construction)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
+    host_staged = dist.get_backend(process_group) != "nccl"
     with torch.no_grad():       # on the tensors themselves (not .data): bumps _version, so cached bf16 copies refresh
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t, src=src, group=process_group)
+            if host_staged and t.is_cuda:
+                h = t.cpu()
+                dist.broadcast(h, src=src, group=process_group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=process_group)
