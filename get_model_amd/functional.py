@@ -141,6 +141,40 @@ class _SideStream:
             self.used = False
 
 
+class _GradHandoff:
+    """dz / bias-gradient of a block's fc2 branch, produced early by its CONSUMER's LayerNorm backward.
+
+    Block i+1 (or the final norm) ends its backward with the LayerNorm-backward kernel that writes dx, the fp32
+    gradient of block i's output.  Block i would start by reading dx again to form dz2 = bf16(scale2 * dx) and its
+    column sums (`scale_cast`, 39 us per layer at the bench shape); the LayerNorm-backward kernel can emit both on
+    the way out.  The downstream backward stores them here keyed by the dx tensor it returns (kept alive, so its
+    address cannot be reused) and by the DropPath scale it used; block i takes them only if the gradient it
+    receives IS that tensor and its own scale2 IS that scale -- anything else (hooks, gradient accumulation from
+    several consumers, blocks wired differently) falls back to scale_cast."""
+
+    def __init__(self):
+        self.slot = None
+
+    def put(self, dx, scale, dz, dbias):
+        self.slot = (dx, scale, dz, dbias)
+
+    def take(self, dx_out, scale):
+        slot, self.slot = self.slot, None
+        if slot is None or not _USE_HANDOFF:
+            return None
+        dx, sc, dz, dbias = slot
+        same_scale = (sc is None and scale is None) or (sc is not None and scale is not None and
+                                                         sc.data_ptr() == scale.data_ptr() and sc.shape == scale.shape)
+        if same_scale and dx.data_ptr() == dx_out.data_ptr() and dx.numel() == dx_out.numel() and \
+                dx_out.dtype == torch.float32:
+            return dz, dbias
+        return None
+
+
+_USE_HANDOFF = os.environ.get("GETMI_HANDOFF", "1") != "0"      # 0: always scale_cast (A/B measurements)
+HANDOFF = _GradHandoff()
+
+
 def _pad_to(n, m):
     return (n + m - 1) // m * m
 
@@ -204,7 +238,9 @@ class EncoderBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
-                scale1, scale2, num_heads, eps):
+                scale1, scale2, num_heads, eps, up_block=False, up_scale=None):
+        """up_block / up_scale: x is the output of another EncoderBlock whose fc2-branch DropPath factor was
+        up_scale (None = identity): this block's backward then also emits that block's dz2 (see _GradHandoff)."""
         _need_gpu(x)
         B, T, D = x.shape
         M = B * T
@@ -235,6 +271,7 @@ class EncoderBlock(torch.autograd.Function):
                               n1w, n2w)
         ctx.weights = (qkv_w, proj_w, fc1_w, fc2_w)
         ctx.dims = (B, T, D, H, att_scale)
+        ctx.up = (bool(up_block), up_scale)
         return x_out.view(B, T, D)
 
     @staticmethod
@@ -250,7 +287,8 @@ class EncoderBlock(torch.autograd.Function):
         # ---- MLP branch ----
         # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
         #  operand, so it waits only for the operand's producer and the two run side by side)
-        dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+        hit = HANDOFF.take(dx_out, scale2)
+        dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
         dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
@@ -274,10 +312,15 @@ class EncoderBlock(torch.autograd.Function):
             dq_bias = K.colsum_bf16(dqkv[:, :D])          # the K third has no bias (model/transformer.py:53)
         if need[5]:
             dv_bias = K.colsum_bf16(dqkv[:, 2 * D:])
-        dx_in, _, dn1w, dn1b, _ = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid)
+        up_block, up_scale = ctx.up
+        dx_in, dz_up, dn1w, dn1b, dbias_up = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid,
+                                                             rowscale=up_scale if up_block else None,
+                                                             rows_per_sample=T, want_dz=up_block, want_dbias=up_block)
+        if up_block:
+            HANDOFF.put(dx_in, up_scale, dz_up, dbias_up)
         side.join()
         return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
-                dfc1_b, dfc2_w, dfc2_b, None, None, None, None)
+                dfc1_b, dfc2_w, dfc2_b, None, None, None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -285,13 +328,14 @@ class FinalNorm(torch.autograd.Function):
     """encoder.norm: fp32 tokens -> bf16 normalised tokens (consumed by the heads)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps):
+    def forward(ctx, x, w, b, eps, up_block=False, up_scale=None):
         _need_gpu(x)
         B, T, D = x.shape
         x2 = x.detach().reshape(B * T, D).contiguous()
         y, mean, rstd = K.layernorm_fwd(x2, w.detach(), b.detach(), eps)
         ctx.save_for_backward(x2, mean, rstd, w)
         ctx.dims = (B, T, D)
+        ctx.up = (bool(up_block), up_scale)      # as in EncoderBlock.forward
         return y.view(B, T, D)
 
     @staticmethod
@@ -301,8 +345,13 @@ class FinalNorm(torch.autograd.Function):
         dy = dy.reshape(B * T, D)
         if dy.dtype != BF16:
             dy = dy.to(BF16)
-        dx, _, dw, db, _ = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach())
-        return dx.view(B, T, D), dw, db, None
+        up_block, up_scale = ctx.up
+        dx, dz_up, dw, db, dbias_up = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach(),
+                                                      rowscale=up_scale if up_block else None, rows_per_sample=T,
+                                                      want_dz=up_block, want_dbias=up_block)
+        if up_block:
+            HANDOFF.put(dx, up_scale, dz_up, dbias_up)
+        return dx.view(B, T, D), dw, db, None, None, None
 
 
 class ExpressionHeadSoftplus(torch.autograd.Function):

@@ -102,18 +102,24 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.gamma_1, self.gamma_2 = None, None
 
-    def forward(self, x, attention_mask=None, attention_bias=None):
+    def forward(self, x, attention_mask=None, attention_bias=None, drop_path_factors=None, upstream=None):
+        """upstream: the Block whose output x is (set by GETTransformer.forward; lets this block's backward hand that
+        block the bf16 gradient of its MLP branch, functional._GradHandoff)."""
         if attention_mask is not None or attention_bias is not None:
             raise NotImplementedError("attention mask / bias are not taken on the region path "
                                       "(model/model.py:574 calls the encoder without them)")
         s1 = s2 = None
-        if isinstance(self.drop_path, DropPath):
+        if drop_path_factors is not None:      # drawn for all blocks at once by GETTransformer.forward
+            s1, s2 = drop_path_factors
+        elif isinstance(self.drop_path, DropPath):
             s1 = self.drop_path.factor(x.shape[0], x.device)
             s2 = self.drop_path.factor(x.shape[0], x.device)
         a, m = self.attn, self.mlp
+        self.last_scale2 = s2
         x = Fn.EncoderBlock.apply(x, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.q_bias, a.v_bias,
                                   a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight,
-                                  m.fc1.bias, m.fc2.weight, m.fc2.bias, s1, s2, a.num_heads, self.norm1.eps)
+                                  m.fc1.bias, m.fc2.weight, m.fc2.bias, s1, s2, a.num_heads, self.norm1.eps,
+                                  upstream is not None, None if upstream is None else upstream.last_scale2)
         return x, None
 
 
@@ -145,11 +151,31 @@ class GETTransformer(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _draw_drop_path(self, batch, device):
+        """All stochastic-depth factors of one forward from ONE uniform draw ([L, 2, B]; 3 launches instead of two
+        bernoulli + divide per block).  None when not training, when nothing drops, or when a test injected masks
+        (then every block draws / pops its own, DropPath.factor)."""
+        if not self.training:
+            return None
+        dps = [blk.drop_path for blk in self.blocks]
+        if any(isinstance(d, DropPath) and d.injected for d in dps):
+            return None
+        probs = [d.drop_prob if isinstance(d, DropPath) else 0.0 for d in dps]
+        if max(probs) == 0.0:
+            return None
+        keep = torch.tensor([1.0 - p for p in probs], dtype=torch.float32, device=device).view(-1, 1, 1)
+        f = (torch.rand(len(dps), 2, batch, device=device) < keep).to(torch.float32) / keep
+        return [None if p == 0.0 else (f[i, 0], f[i, 1]) for i, p in enumerate(probs)]
+
     def forward(self, x, mask=None, return_attns=False, bias=None):
         if return_attns:
             raise NotImplementedError("return_attns=True would materialise the [B,H,T,T] probabilities the fused "
                                       "attention kernel never forms")
-        for blk in self.blocks:
-            x, _ = blk(x, mask, bias)
-        x = Fn.FinalNorm.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        factors = self._draw_drop_path(x.shape[0], x.device)
+        prev = None
+        for i, blk in enumerate(self.blocks):
+            x, _ = blk(x, mask, bias, drop_path_factors=None if factors is None else factors[i], upstream=prev)
+            prev = blk
+        x = Fn.FinalNorm.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, prev is not None,
+                               None if prev is None else prev.last_scale2)
         return x, None
