@@ -57,17 +57,18 @@ struct AttnFwdArgs {
     float scale;
 };
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 8192];   // [buf][K|V][64 keys][128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H;
-    const int nqb = (T + 127) >> 7;
+    const int nw = blockDim.x >> 6;                 // waves per workgroup (4..8, chosen by the launcher): 32 queries each
+    const int nqb = (T + 32 * nw - 1) / (32 * nw);
     const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
     const int b = bh / H, h = bh - b * H;
     const size_t rs = (size_t)3 * H * HD;   // elements per token row of qkv
     const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * 32 * nw + wave * 32;
     const int r = lane & 31, h2 = lane >> 5;
 
     bf16x8 qf[4];
@@ -79,13 +80,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnFwdArgs p) {
     }
 
     const int nchunk = (T + 63) >> 6;
-    // staging: K chunk = 8 wave-instructions (8 rows x 128 B each); 2 per wave, same for V
+    // staging: K chunk = 8 wave-instructions (8 rows x 128 B each) spread over the waves, same for V
     auto stage = [&](int buf, int c) {
         char* kb = smem + buf * 16384;
         char* vb = kb + 8192;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int I = wave * 2 + j;
+        for (int I = wave; I < 8; I += nw) {
             const int row = I * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ swz128(row);
             const int key = min(c * 64 + row, T - 1);
@@ -460,8 +459,20 @@ int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_fwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "attn_fwd: pointers must be 16-byte aligned");
     AttnFwdArgs a{qkv, out, lse, B, T, H, scale};
-    const int nqb = (T + 127) / 128;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H * nqb), dim3(256), 0, st, a);
+    // waves (= 32-query groups) per workgroup: 8 (256 queries: K/V of a (b, h) staged once for T <= 256, one staging
+    // instruction per wave and chunk) unless 4 already cover T.  Measured at T = 201: 104 us vs 111 (4 waves) and 118
+    // (7 waves: the staging no longer divides evenly); T = 2001: 366 vs 375.  GETMI_ATTN_FWD_WAVES overrides (4..8)
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("GETMI_ATTN_FWD_WAVES");
+        forced = e ? atoi(e) : 0;
+    }
+    int nw = T > 128 ? 8 : 4;
+    if (forced >= 4 && forced <= 8) nw = forced;
+    if (nw < 4) nw = 4;
+    if (nw > 8) nw = 8;
+    const int nqb = (T + 32 * nw - 1) / (32 * nw);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H * nqb), dim3(64 * nw), 0, st, a);
     GETMI_CHECK_LAUNCH("attn_fwd");
     return GETMI_OK;
 }
