@@ -193,6 +193,7 @@ struct AttnBwdArgs {
     const float* lse;     // [B,H,T]
     bf16_t* dqkv;         // [B,T,3,H,64]
     float* dq_acc;        // [nkb][B,T,H,64] fp32 partial dQ per 256-key block, only when T > 256
+    float* bias_partial;  // [2][B*nkb][H*64] fp32: per-workgroup column sums of dQ (k=0) and dV (k=1), or null
     int B, T, H;
     float scale;
 };
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
     bf16x8 kfr[4];   // this wave's K rows as the B operand of S = Q.K^T           (slice-invariant, kept in VGPRs)
     bf16x8 ktf[8];   // K^T fragments of all 256 keys for this wave's dQ d-block   (slice-invariant, kept in VGPRs)
+    f32x4 dqs = {0.f, 0.f, 0.f, 0.f};   // running sum over queries of this wave's dQ tiles (q_bias gradient)
     float* stf = reinterpret_cast<float*>(smem + BW_ST);
     int dsbuf = 0;
 
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                         acc = MFMA16(ktf[ks], dst, acc);   // D[d][q] = sum_key K[key][d] dS[q][key]
                     }
                 }
+                dqs += acc;        // rows of padded queries are exactly 0 (P = 0 there)
                 const int q = qc + sl * 32 + qh * 16 + (lane & 15);
                 const int d0 = dblk * 16 + (lane >> 4) * 4;
                 if (q < T) {
@@ -420,6 +423,57 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
         }
     }
 
+    if (p.bias_partial != nullptr) {
+        // ---- q_bias / v_bias gradients = column sums of dQ / dV over all tokens: this workgroup's share, from the
+        //      fp32 accumulators (the q_bias gradient is a cancellation sum; summing the bf16-rounded dqkv loses it).
+        //      dV: lane = key, registers = d -> reduce over the 32 lanes of each half wave; columns of padded keys
+        //      are exactly 0.  dQ: lane&15 = query -> reduce over 16 lanes.  Then across waves through LDS.
+        __syncthreads();                                   // every wave is done with the dS images: reuse them
+        float* red = reinterpret_cast<float*>(smem + BW_DS);          // [8 waves][64] dV | [2 q-halves][64] dQ at +512
+        {
+            // butterfly reduce-scatter over the 32 lanes of a half wave: 16+8+4+2+1 exchanges instead of 32 x 5;
+            // lane r ends with the sum over keys of accumulator register r (= db*16 + i)
+            float v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = dv[k >> 4][k & 15];
+#pragma unroll
+            for (int m = 16, n = 32; m > 0; m >>= 1, n >>= 1) {
+                const bool up = (lane & m) != 0;
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) {
+                    const float lo = v[j], hi = v[j + n / 2];
+                    v[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, 64);
+                }
+            }
+            const int i = r & 15;
+            red[wave * 64 + (r >> 4) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = v[0];
+        }
+        {
+            // dQ: 4 registers over the 16 lanes that share (lane >> 4): reduce-scatter over lane bits 3, 2, then sum
+            // over bits 1, 0; lanes with (lane & 3) == 0 hold register j = (lane >> 2) & 3
+            const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
+            float a0 = (u8 ? dqs[2] : dqs[0]) + __shfl_xor(u8 ? dqs[0] : dqs[2], 8, 64);
+            float a1 = (u8 ? dqs[3] : dqs[1]) + __shfl_xor(u8 ? dqs[1] : dqs[3], 8, 64);
+            float v = (u4 ? a1 : a0) + __shfl_xor(u4 ? a0 : a1, 4, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 1, 64);
+            const int j = ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            if ((lane & 3) == 0) red[512 + (wave & 1) * 64 + (wave >> 1) * 16 + (lane >> 4) * 4 + j] = v;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int d = tid & 63;
+            float v;
+            if (tid < 64) v = (red[512 + d] + red[576 + d]) * p.scale;
+            else {
+                v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
+            }
+            const size_t R = (size_t)p.B * nkb;
+            p.bias_partial[((size_t)(tid >> 6) * R + (size_t)b * nkb + kbi) * (H * HD) + h * HD + d] = v;
+        }
+    }
     if (mykey < T) {
         bf16_t* krow = p.dqkv + ((size_t)b * T + mykey) * rs + H * HD + h * HD;
         bf16_t* vrow = krow + H * HD;
@@ -477,16 +531,24 @@ int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T
     return GETMI_OK;
 }
 
-size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
-    return T > 256 ? (size_t)((T + 255) / 256) * B * T * H * HD * sizeof(float) : 0;   // per-key-block dQ slabs
+static size_t attn_bwd_slab_bytes(int B, int T, int H) {
+    const size_t n = T > 256 ? (size_t)((T + 255) / 256) * B * T * H * HD * sizeof(float) : 0;   // per-key-block dQ slabs
+    return (n + 255) & ~(size_t)255;
 }
+size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
+    // + per-workgroup column sums of dQ and dV (bias gradients): [2][B * key blocks][H*64] fp32
+    return attn_bwd_slab_bytes(B, T, H) + (size_t)2 * B * ((T + 255) / 256) * H * HD * sizeof(float);
+}
+int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
+                         hipStream_t st);
 
 int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        int B, int T, int H, float scale, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
+                        size_t workspace_bytes, hipStream_t st) {
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_attn_bwd_workspace_bytes(B, T, H), "attn_bwd: workspace too small");
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
-                        ((uintptr_t)out % 16 == 0) && (T <= 256 || (uintptr_t)workspace % 256 == 0),
+                        ((uintptr_t)out % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
                     "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
     float* dq_acc = nullptr;
     if (T > 256) dq_acc = reinterpret_cast<float*>(workspace);   // every slab element is written by its key block
@@ -496,7 +558,10 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS);
         attr_set = true;
     }
-    AttnBwdArgs a{qkv, out, dout, lse, dqkv, dq_acc, B, T, H, scale};
+    const bool want_bias = dq_bias != nullptr || dv_bias != nullptr;
+    float* bias_partial = want_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + attn_bwd_slab_bytes(B, T, H))
+                                    : nullptr;
+    AttnBwdArgs a{qkv, out, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale};
     const int nkb = (T + 255) / 256;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");
@@ -506,6 +571,14 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(attn_dq_convert_kernel, dim3(grid), dim3(256), 0, st, dq_acc, dqkv, (size_t)B * T, H, nkb);
         GETMI_CHECK_LAUNCH("attn_dq_convert");
+    }
+    if (want_bias) {
+        // every (row, column) of both partial matrices was written by exactly one workgroup
+        const int R = B * nkb, C = H * HD;
+        const float* pq = bias_partial;
+        if (dq_bias && dv_bias) return getmi_colreduce_impl(pq, dq_bias, dv_bias, nullptr, R, C, 0, st);
+        if (dq_bias) return getmi_colreduce_impl(pq, dq_bias, nullptr, nullptr, R, C, 0, st);
+        return getmi_colreduce_impl(pq + (size_t)R * C, dv_bias, nullptr, nullptr, R, C, 0, st);
     }
     return GETMI_OK;
 }

@@ -22,8 +22,8 @@ int getmi_ln_bwd_impl(const bf16_t*, const float*, const float*, const float*, c
                       int, float*, bf16_t*, float*, float*, float*, int, int, int, void*, size_t, hipStream_t);
 int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, float*, int, int, int, float, hipStream_t);
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H);
-int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, int, int, int, float, void*,
-                        size_t, hipStream_t);
+int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, float*, float*, int, int, int,
+                        float, void*, size_t, hipStream_t);
 int getmi_cast_pad_impl(const float*, bf16_t*, size_t, int, int, hipStream_t);
 int getmi_cast_transpose_impl(const float*, bf16_t*, int, int, hipStream_t);
 int getmi_qkv_bias_impl(const float*, const float*, float*, int, hipStream_t);
@@ -111,10 +111,11 @@ int getmi_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, in
     return getmi_attn_fwd_impl(BF(qkv), BFW(out), lse, B, T, H, scale, ST(stream));
 }
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H) { return getmi_attn_bwd_workspace_bytes(B, T, H); }
-int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T,
-                        int H, float scale, void* workspace, size_t workspace_bytes, void* stream) {
-    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(dout), lse, BFW(dqkv), B, T, H, scale, workspace, workspace_bytes,
-                               ST(stream));
+int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(dout), lse, BFW(dqkv), dq_bias, dv_bias, B, T, H, scale, workspace,
+                               workspace_bytes, ST(stream));
 }
 int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream) {
     return getmi_fill_cls_impl(x0, cls_token, B, T, D, ST(stream));

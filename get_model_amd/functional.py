@@ -303,15 +303,16 @@ class EncoderBlock(torch.autograd.Function):
         dproj_w = side.run(lambda: K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w))) if need[6] else None
         da = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dz1, w_bf16_t(proj_w), da)                       # dz1 @ Wproj
-        dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
+        # q_bias / v_bias gradients (the K third has no bias, model/transformer.py:53) come out of the attention
+        # backward's fp32 accumulators
+        dq_bias = dv_bias = None
+        if need[4] or need[5]:
+            dqkv, dq_bias, dv_bias = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, want_bias=True)
+        else:
+            dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
         dqkv_w = side.run(lambda: K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w))) if need[3] else None
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
-        dq_bias = dv_bias = None
-        if need[4]:
-            dq_bias = K.colsum_bf16(dqkv[:, :D])          # the K third has no bias (model/transformer.py:53)
-        if need[5]:
-            dv_bias = K.colsum_bf16(dqkv[:, 2 * D:])
         up_block, up_scale = ctx.up
         dx_in, dz_up, dn1w, dn1b, dbias_up = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid,
                                                              rowscale=up_scale if up_block else None,

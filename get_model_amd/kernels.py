@@ -152,14 +152,17 @@ def attention_fwd(qkv, B, T, H, scale):
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, T, H, scale):
+def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False):
+    """-> dqkv, or (dqkv, dq_bias [H*64], dv_bias [H*64]) with want_bias (column sums of the Q / V thirds, fp32)."""
     _chk(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)
+    dqb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
+    dvb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
     e0 = _prof_begin()
-    lib.call("getmi_attention_bwd", qkv, out, dout, lse, dqkv, B, T, H, float(scale), ws, ws.numel())
+    lib.call("getmi_attention_bwd", qkv, out, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), ws, ws.numel())
     _prof_end(e0, "attn_bwd_kernel(+delta)", 10.0 * B * H * T * T * 64)
-    return dqkv
+    return (dqkv, dqb, dvb) if want_bias else dqkv
 
 
 def fill_cls(x0, cls_token, B, T, D):

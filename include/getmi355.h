@@ -73,8 +73,11 @@ int getmi_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, 
 /* ---- attention (model/transformer.py:58-96), packed qkv[B,T,3,H,64] bf16, head_dim 64 ---------- */
 int getmi_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale, void* stream);
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H);
-int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-                        int T, int H, float scale, void* workspace, size_t workspace_bytes, void* stream);
+/* dq_bias / dv_bias (each [H*64] fp32, may be null): column sums over all tokens of the Q and V thirds of dqkv, taken
+ * from the fp32 accumulators -- the gradients of Attention.q_bias / v_bias (model/transformer.py:52-57). */
+int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- region embed glue (model/model.py:520-525,571-573) ---------------------------------------- */
 int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream);

@@ -196,6 +196,16 @@ def test_attention_fwd_bwd(K, B, T, H):
     assert err <= 1.5e-2 * g.abs().max().item(), f"attn.dqkv err {err:.3e} vs max {g.abs().max().item():.3e}"
     cos = F.cosine_similarity(dqkv.float().flatten(), g.flatten(), dim=0).item()
     assert cos > 0.9995, f"attn.dqkv cosine {cos}"
+    # fused bias gradients: column sums of the Q / V thirds over all tokens, from the fp32 accumulators; the same
+    # dqkv comes back, and the sums match the fp32 reference (scaled by the size of the summands: dq sums cancel)
+    dqkv2, dqb, dvb = K.attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=True)
+    assert torch.equal(dqkv2, dqkv)
+    D = H * 64
+    for name, got, third in (("dq_bias", dqb, g[:, :D]), ("dv_bias", dvb, g[:, 2 * D:])):
+        ref_sum = third.sum(0)
+        tol = 4e-3 * third.abs().sum(0).max().item()
+        err = (got - ref_sum).abs().max().item()
+        assert err <= tol, f"attn.{name} err {err:.3e} > {tol:.3e}"
 
 
 def test_attention_online_softmax_rescale(K):
