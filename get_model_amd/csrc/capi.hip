@@ -72,7 +72,7 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
                mask, mask_token, regions_per_sample, nullptr};
     if (dbias) {
-        GETMI_CHECK_ARG(epi == 3, "gemm_tn: dbias (fused column sums) is only produced by the DGELU epilogue");
+        GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
         GETMI_CHECK_ARG(workspace && workspace_bytes >= getmi_gemm_tn_workspace_bytes(M, N) &&
                             ((uintptr_t)workspace % 16 == 0),
                         "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");

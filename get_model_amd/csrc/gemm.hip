@@ -22,7 +22,25 @@ enum {
     EPI_DGELU = 3,        // out0(bf16) = acc * gelu'(aux)
     EPI_EMBED = 4,        // out0(f32)[b*T+1+n] = mask ? mask_token : acc+bias
     EPI_F32 = 5,          // out0(f32) = acc (+bias)
+    EPI_BIAS_GELUG = 6,   // u = acc+bias ; out0(bf16)=gelu'(u) ; out1(bf16)=gelu(u)   (training forward of fc1)
+    EPI_DMUL = 7,         // out0(bf16) = acc * aux   (+ column sums)                  (its backward: aux = gelu'(u))
 };
+// The training path stores gelu'(u) instead of u: both come out of one gelu_parts() in the forward epilogue, and the
+// backward epilogue becomes a multiply (the dGELU form re-evaluates erf per element: ~40 us of a 360-us GEMM).
+template <int EPI> struct EpiKind {
+    static constexpr bool gelu = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELUG);
+    static constexpr bool dgelu = (EPI == EPI_DGELU || EPI == EPI_DMUL);
+};
+template <int EPI>
+__device__ __forceinline__ float dgelu_factor(float a) { return EPI == EPI_DMUL ? a : dgelu_f(a); }
+// (first output, gelu(x)) of the two-output forward epilogues
+template <int EPI>
+__device__ __forceinline__ void gelu_pair(float x, float& o0, float& o1) {
+    float Phi, pdf;
+    gelu_parts(x, Phi, pdf);
+    o1 = x * Phi;
+    o0 = (EPI == EPI_BIAS_GELUG) ? fmaf(x, pdf, Phi) : x;
+}
 
 struct GemmArgs {
     const bf16_t* A;
@@ -56,7 +74,7 @@ struct GemmArgs {
 template <int EPI, int MT, int NT, int MS, int NS, typename Get>
 __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, int em, int en, int prow = 0) {
     float4 bv[NT];
-    const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;
+    const bool has_bias = !EpiKind<EPI>::dgelu && p.bias != nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = min(en + nt * NS, p.N - 4);
@@ -89,7 +107,7 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
             }
         return;
     }
-    if (EPI == EPI_DGELU) {
+    if (EpiKind<EPI>::dgelu) {
         uint2 uv[MT][NT];
         float4 cs[NT];
 #pragma unroll
@@ -108,8 +126,8 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 if (m < p.M && n < p.N) {
                     const f32x4 v = acc_get(mt, nt);
                     const uint2 u = uv[mt][nt];
-                    const float d0 = v[0] * dgelu_f(bf2f(u.x & 0xffff)), d1 = v[1] * dgelu_f(bf2f(u.x >> 16));
-                    const float d2 = v[2] * dgelu_f(bf2f(u.y & 0xffff)), d3 = v[3] * dgelu_f(bf2f(u.y >> 16));
+                    const float d0 = v[0] * dgelu_factor<EPI>(bf2f(u.x & 0xffff)), d1 = v[1] * dgelu_factor<EPI>(bf2f(u.x >> 16));
+                    const float d2 = v[2] * dgelu_factor<EPI>(bf2f(u.y & 0xffff)), d3 = v[3] * dgelu_factor<EPI>(bf2f(u.y >> 16));
                     *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(d0, d1, d2, d3);
                     cs[nt].x += d0; cs[nt].y += d1; cs[nt].z += d2; cs[nt].w += d3;
                 }
@@ -144,10 +162,12 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
             } else if (EPI == EPI_F32) {
                 *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (EPI == EPI_BIAS_GELU) {
-                *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) =
-                    pack4bf(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+            } else if (EpiKind<EPI>::gelu) {
+                float h0, h1, h2, h3, g0, g1, g2, g3;
+                gelu_pair<EPI>(v[0], h0, g0); gelu_pair<EPI>(v[1], h1, g1);
+                gelu_pair<EPI>(v[2], h2, g2); gelu_pair<EPI>(v[3], h3, g3);
+                *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(h0, h1, h2, h3);
+                *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) = pack4bf(g0, g1, g2, g3);
             } else if (EPI == EPI_EMBED) {
                 const int b = m / p.regions_per_sample, r = m - b * p.regions_per_sample;
                 const size_t orow = (size_t)b * (p.regions_per_sample + 1) + 1 + r;
@@ -445,7 +465,7 @@ __device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
 
 template <int EPI>
 struct EpiStores {   // buffer-store instructions per wave and output tile (lower bound used in the counted waits)
-    static constexpr int value = (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID) ? 32 : 16;
+    static constexpr int value = (EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 32 : 16;
 };
 
 // wait until at most 2*halftiles (+ EXTRA) vector-memory operations of this wave are outstanding
@@ -499,7 +519,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
     float4 bv[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) bv[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI != EPI_DGELU && bias_lds != nullptr) {
+    if (!EpiKind<EPI>::dgelu && bias_lds != nullptr) {
         // inline asm on purpose: a compiler-visible ds_read of LDS-DMA-written memory makes hipcc emit
         // s_waitcnt vmcnt(0) (draining the operand prefetch and the previous tile's stores).  The bias DMA is
         // known complete here: it was issued >= 12 vector-memory operations before the last counted wait.
@@ -570,7 +590,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         uint2 uv[4][4];
-        if (EPI == EPI_DGELU) {
+        if (EpiKind<EPI>::dgelu) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -583,28 +603,37 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             const int ab = half * 4 + a;
             const bool mok = (em + ab * 16) < p.M;
             // bf16 output(s): 16 rows x 64 columns (128 B per row) per stage pass
+            u32x2 qv[4], qg[4];
 #pragma unroll
-            for (int outp = 0; outp < (EPI == EPI_BIAS_GELU ? 2 : 1); ++outp) {
-                u32x2 qv[4];
-                u32x4 dd[2];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    f32x4 v = acc[ab][b];
-                    float d0, d1, d2, d3;
-                    if (EPI == EPI_DGELU) {
-                        const uint2 u = uv[a][b];
-                        d0 = v[0] * dgelu_f(bf2f(u.x & 0xffff)); d1 = v[1] * dgelu_f(bf2f(u.x >> 16));
-                        d2 = v[2] * dgelu_f(bf2f(u.y & 0xffff)); d3 = v[3] * dgelu_f(bf2f(u.y >> 16));
-                        if (mok && (en + b * 16) < p.N) { cs[b].x += d0; cs[b].y += d1; cs[b].z += d2; cs[b].w += d3; }
-                    } else {
-                        d0 = v[0] + bv[b].x; d1 = v[1] + bv[b].y; d2 = v[2] + bv[b].z; d3 = v[3] + bv[b].w;
-                        if (outp == 1) { d0 = gelu_f(d0); d1 = gelu_f(d1); d2 = gelu_f(d2); d3 = gelu_f(d3); }
+            for (int b = 0; b < 4; ++b) {
+                const f32x4 v = acc[ab][b];
+                float d0, d1, d2, d3;
+                if (EpiKind<EPI>::dgelu) {
+                    const uint2 u = uv[a][b];
+                    d0 = v[0] * dgelu_factor<EPI>(bf2f(u.x & 0xffff)); d1 = v[1] * dgelu_factor<EPI>(bf2f(u.x >> 16));
+                    d2 = v[2] * dgelu_factor<EPI>(bf2f(u.y & 0xffff)); d3 = v[3] * dgelu_factor<EPI>(bf2f(u.y >> 16));
+                    if (mok && (en + b * 16) < p.N) { cs[b].x += d0; cs[b].y += d1; cs[b].z += d2; cs[b].w += d3; }
+                } else {
+                    d0 = v[0] + bv[b].x; d1 = v[1] + bv[b].y; d2 = v[2] + bv[b].z; d3 = v[3] + bv[b].w;
+                    if (EpiKind<EPI>::gelu) {
+                        float g0, g1, g2, g3;
+                        gelu_pair<EPI>(d0, d0, g0); gelu_pair<EPI>(d1, d1, g1);
+                        gelu_pair<EPI>(d2, d2, g2); gelu_pair<EPI>(d3, d3, g3);
+                        qg[b] = pack4bf_v(g0, g1, g2, g3);
                     }
-                    qv[b] = pack4bf_v(d0, d1, d2, d3);
                 }
+                qv[b] = pack4bf_v(d0, d1, d2, d3);
+            }
+#pragma unroll
+            for (int outp = 0; outp < (EpiKind<EPI>::gelu ? 2 : 1); ++outp) {
+                u32x4 dd[2];
                 // 8-byte piece of (b, c): columns b*16 + c*4 .. +3 -> 16-B chunk (b*2 + (c>>1)), half (c&1)
-                stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qv[0], qv[1], qv[2],
-                                   qv[3], dd[0], dd[1]);
+                if (outp == 0)
+                    stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qv[0], qv[1],
+                                       qv[2], qv[3], dd[0], dd[1]);
+                else
+                    stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qg[0], qg[1],
+                                       qg[2], qg[3], dd[0], dd[1]);
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
                     const int row = ps * 8 + rrow;
@@ -615,7 +644,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             }
         }
     }
-    if (EPI == EPI_DGELU && p.colsum) {
+    if (EpiKind<EPI>::dgelu && p.colsum) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             float4 cc = cs[b];
@@ -717,7 +746,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     const int b_base = 32768 + (wn * 64) * 128;
 
     // per-wave LDS copy of the current tile's bias row segment [n0, n0+256): one 1-KiB LDS-DMA per wave and tile
-    const bool has_bias = (EPI != EPI_DGELU) && p.bias != nullptr;      // workgroup-uniform
+    const bool has_bias = !EpiKind<EPI>::dgelu && p.bias != nullptr;    // workgroup-uniform
     char* bias_img = smem + G2_LDS;                      // 1 KiB shared image: every wave DMA-writes the same values
     char* stage = smem + G2_LDS + 1024 + wave * 2048;    // 2 KiB wave-private store stage
     auto stage_bias = [&](int iter) {
@@ -1230,7 +1259,7 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
     if (use_big_tile(a)) {
         // BIAS_RESID stays on the one-tile-per-workgroup kernel: its epilogue LOADS the fp32 residual (ordinary loads
         // force a vmcnt(0) drain) and measured 302 vs 278 us (fc2) persistent vs not.
-        constexpr bool can_persist = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_DGELU);
+        constexpr bool can_persist = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu);
         const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
         const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
                             (size_t)a.M * a.ldo * esz < 0xF0000000ull;
@@ -1283,6 +1312,12 @@ int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
             GETMI_CHECK_ARG(!a.mask || a.mask_token, "gemm_tn: embed mask needs mask_token");
             return launch_gemm_tn<EPI_EMBED>(a, st);
         case EPI_F32: return launch_gemm_tn<EPI_F32>(a, st);
+        case EPI_BIAS_GELUG:
+            GETMI_CHECK_ARG(a.out1 && a.bias, "gemm_tn: bias_gelu_grad needs out1 and bias");
+            return launch_gemm_tn<EPI_BIAS_GELUG>(a, st);
+        case EPI_DMUL:
+            GETMI_CHECK_ARG(a.aux && a.ldaux % 4 == 0, "gemm_tn: dmul needs aux");
+            return launch_gemm_tn<EPI_DMUL>(a, st);
     }
     getmi_set_error("gemm_tn: unknown epilogue %d", epi);
     return GETMI_ERR_ARG;

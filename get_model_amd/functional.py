@@ -263,7 +263,8 @@ class EncoderBlock(torch.autograd.Function):
         Fh = fc1_w.shape[0]
         u = torch.empty(M, Fh, dtype=BF16, device=dev)
         g = torch.empty(M, Fh, dtype=BF16, device=dev)
-        K.gemm_tn(K.EPI_BIAS_GELU, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach())
+        # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply
+        K.gemm_tn(K.EPI_BIAS_GELUG, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach())
         x_out = torch.empty(M, D, dtype=torch.float32, device=dev)
         K.gemm_tn(K.EPI_BIAS_RESID, g, w_bf16(fc2_w), x_out, bias=fc2_b.detach(), resid=x_mid, rowscale=scale2,
                   rows_per_sample=T)
@@ -292,7 +293,7 @@ class EncoderBlock(torch.autograd.Function):
         dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
-        K.gemm_tn(K.EPI_DGELU, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)  # (dz2 @ W2) * gelu'(u), + column sums
+        K.gemm_tn(K.EPI_DMUL, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)   # (dz2 @ W2) * gelu'(.), + column sums
         dfc1_w = side.run(lambda: K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w))) if need[10] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1

@@ -7,14 +7,14 @@ import torch
 
 from . import lib
 
-EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_EMBED, EPI_F32 = range(6)
+EPI_BF16, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_DGELU, EPI_EMBED, EPI_F32, EPI_BIAS_GELUG, EPI_DMUL = range(8)
 BF16 = torch.bfloat16
 F32 = torch.float32
 
 # bench.py sets PROFILE = [] to collect (kernel name, algorithmic flops, start event, end event) per GEMM launch,
 # recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
-_EPI_NAMES = ("bf16", "bias_gelu", "bias_resid", "dgelu", "embed", "f32")
+_EPI_NAMES = ("bf16", "bias_gelu", "bias_resid", "dgelu", "embed", "f32", "bias_gelu", "dgelu")   # 6, 7: training forms
 
 
 def _prof_begin():

@@ -47,13 +47,15 @@ int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, 
  *   4 EMBED       out0(f32)[b*(R+1)+1+r] = mask[m] ? mask_token : acc+bias  (R = regions_per_sample)
  *                                                                       modules.py:101-103, model.py:520-525
  *   5 F32         out0(f32) = acc (+bias)                               head_mask: model.py:528
+ *   6 BIAS_GELUG  out0(bf16)=gelu'(u), u=acc+bias ; out1(bf16)=gelu_erf(u)   training form of 1: saves the derivative
+ *   7 DMUL        out0(bf16) = acc * aux                                autograd of :173 with aux = gelu'(u) from 6
  * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned pointers.  Unused pointers may be NULL. */
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0,
                   void* out1, int ldo, const float* bias, const float* resid, const float* rowscale,
                   int rows_per_sample, const void* aux, int ldaux, const uint8_t* mask, const float* mask_token,
                   int regions_per_sample, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
-/* DGELU only: dbias[N] (optional) = column sums of out0 before rounding = bias gradient of the Linear whose
- * pre-activation is `aux` (fc1.bias); needs workspace of getmi_gemm_tn_workspace_bytes(M, N). */
+/* DGELU / DMUL only: dbias[N] (optional) = column sums of out0 before rounding = bias gradient of the Linear whose
+ * pre-activation (or its GELU derivative) is `aux` (fc1.bias); needs workspace of getmi_gemm_tn_workspace_bytes(M, N). */
 size_t getmi_gemm_tn_workspace_bytes(int M, int N);
 /* out[N1,N2] (+)= X[M,N1]^T * Y[M,N2]  (weight gradient; autograd of F.linear).  bf16 operands, fp32 out. */
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2);

@@ -101,6 +101,20 @@ def test_gemm_tn_epilogues(K, M):
     refd = (A.float() @ W.float().t()) * xp.grad
     close(d, refd, 4e-3, 2e-3, "dgelu")
     close(dbias, refd.sum(0), 1e-3, 2e-3 * math.sqrt(M), "dgelu.colsum")
+    # training forms: forward stores gelu'(u) next to gelu(u); backward multiplies by the stored derivative
+    gp = torch.empty_like(o)
+    g2 = torch.empty_like(o)
+    K.gemm_tn(K.EPI_BIAS_GELUG, A, W, gp, out1=g2, bias=bias)
+    assert torch.equal(g2, g)
+    xr = ref.clone().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    close(gp, xr.grad, 4e-3, 1e-3, "gelug.derivative")
+    d2 = torch.empty_like(o)
+    dbias2 = torch.empty(N, device="cuda")
+    K.gemm_tn(K.EPI_DMUL, A, W, d2, aux=pre, dbias=dbias2)
+    refm = (A.float() @ W.float().t()) * pre.float()
+    close(d2, refm, 4e-3, 2e-3, "dmul")
+    close(dbias2, refm.sum(0), 1e-3, 2e-3 * math.sqrt(M), "dmul.colsum")
 
 
 def test_gemm_tn_embed(K):
