@@ -41,9 +41,11 @@ def synthetic_batch(B, N, seed, device):
 _TRAFFIC_GROUPS = {
     "gemm_wgrad_kernel(+reduce_slabs)": (["gemm_wgrad256_kernel", "gemm_wgrad_kernel"], ["reduce_slabs_kernel"]),
     "gemm_tn_kernel<bf16>": (["gemm_tn256p_kernel<0>", "gemm_tn256_kernel<0>", "gemm_tn_kernel<0>"], []),
-    "gemm_tn_kernel<bias_gelu>": (["gemm_tn256p_kernel<1>", "gemm_tn256_kernel<1>", "gemm_tn_kernel<1>"], []),
+    "gemm_tn_kernel<bias_gelu>": (["gemm_tn256p_kernel<1>", "gemm_tn256_kernel<1>", "gemm_tn_kernel<1>",
+                                   "gemm_tn256p_kernel<6>", "gemm_tn256_kernel<6>", "gemm_tn_kernel<6>"], []),
     "gemm_tn_kernel<bias_resid>": (["gemm_tn256p_kernel<2>", "gemm_tn256_kernel<2>", "gemm_tn_kernel<2>"], []),
-    "gemm_tn_kernel<dgelu>": (["gemm_tn256p_kernel<3>", "gemm_tn256_kernel<3>", "gemm_tn_kernel<3>"], []),
+    "gemm_tn_kernel<dgelu>": (["gemm_tn256p_kernel<3>", "gemm_tn256_kernel<3>", "gemm_tn_kernel<3>",
+                               "gemm_tn256p_kernel<7>", "gemm_tn256_kernel<7>", "gemm_tn_kernel<7>"], []),
     "attn_bwd_kernel(+delta)": (["attn_bwd_kernel"], []),
     "attn_fwd_kernel": (["attn_fwd_kernel"], []),
 }
