@@ -1,0 +1,78 @@
+"""Region-batch producer: the dataset rules restated literally, and the device-side batch gather
+against per-item stacking.  CPU (the gather is plain tensor indexing; on the GPU the tables live in HBM)."""
+import numpy as np
+import torch
+
+from get_model_amd import data as D
+
+
+def test_region_motif_rules():
+    st = D.make_synthetic_store(num_peaks=800, celltypes=("a",), seed=1)
+    rm = D.RegionMotif(st, "a")
+    keep = np.nonzero(st["atpm/a"])[0]                       # drop_zero_atpm
+    assert rm.num_peaks == len(keep) and np.array_equal(rm.atpm, st["atpm/a"][keep])
+    raw = st["data"][keep]
+    ref = raw / raw.max(axis=0)                              # per-column max over the KEPT peaks, clipped to 1
+    ref[ref > 1] = 1
+    assert np.allclose(rm.normalized_data, ref) and rm.normalized_data.max() <= 1.0
+    low = rm.atpm < D.EXPRESSION_ATAC_CUTOFF                 # expression zeroed where aTPM < 0.05
+    assert low.any() and (rm.expression_positive[low] == 0).all() and (rm.expression_negative[low] == 0).all()
+    assert np.array_equal(rm.expression_positive[~low], st["expression_positive/a"][keep][~low])
+    assert rm.chromosome[0] == "chr1" and rm.end[0] - rm.start[0] == 400
+    assert D._chromosome_splitter(["chr1", "chr2", "chr3"], "chr2,chr3", True) == ["chr1"]
+    assert D._chromosome_splitter(["chr1", "chr2", "chr3"], "chr2,chr3", False) == ["chr2", "chr3"]
+    assert D._chromosome_splitter(["chr1", "chr2"], None, False) == ["chr1", "chr2"]
+
+
+def test_windows_and_items():
+    st = D.make_synthetic_store(num_peaks=3000, celltypes=("a", "b"), seed=2)
+    ds = D.RegionMotifDataset(st, celltypes="a,b", sampling_step=50, num_region_per_sample=200, seed=3,
+                              quantitative_atac=True)
+    assert len(ds) > 40
+    for ct, s, e in ds.sample_indices:
+        rm = ds.region_motifs[ct]
+        assert e - s == 200 and e < rm.num_peaks
+        assert 0 <= rm.end[e] - rm.start[s] <= D.MAX_WINDOW_BP
+    it = ds[5]
+    ct, s, e = ds.sample_indices[5]
+    rm = ds.region_motifs[ct]
+    assert it["region_motif"].shape == (200, 283) and it["region_motif"].dtype == np.float32
+    assert np.allclose(it["region_motif"][:, -1], rm.atpm[s:e] / rm.atpm[s:e].max())
+    assert np.allclose(it["region_motif"][:, :282], rm.normalized_data[s:e])
+    assert it["exp_label"].shape == (200, 2) and np.array_equal(it["mask"], rm.tss[s:e])
+    # leave-out cell types: train drops them, eval keeps only them
+    tr = D.RegionMotifDataset(st, leave_out_celltypes="b", is_train=True, num_region_per_sample=200, seed=0)
+    ev = D.RegionMotifDataset(st, leave_out_celltypes="b", is_train=False, num_region_per_sample=200, seed=0)
+    assert list(tr.region_motifs) == ["a"] and list(ev.region_motifs) == ["b"]
+    ones = D.RegionMotifDataset(st, celltypes="a", num_region_per_sample=200, seed=0)[0]["region_motif"][:, -1]
+    assert (ones == 1).all()
+
+
+def test_batch_producer_matches_per_item_stacking():
+    st = D.make_synthetic_store(num_peaks=3000, celltypes=("a", "b"), seed=4)
+    for quant in (False, True):
+        ds = D.RegionMotifDataset(st, sampling_step=50, num_region_per_sample=200, seed=5, quantitative_atac=quant)
+        prod = D.RegionBatchProducer(ds, batch_size=8, device="cpu", shuffle=True, seed=7, rank=1, world=2)
+        order = prod._order()
+        assert len(order) == len(ds) // 2          # rank 1 of 2 takes the odd positions of the shuffled list
+        nb = 0
+        for b, batch in enumerate(prod):
+            ids = order[b * 8:(b + 1) * 8]
+            items = [ds[int(i)] for i in ids]
+            ref_motif = np.stack([it["region_motif"] for it in items])
+            assert batch["region_motif"].shape == (8, 200, 283)
+            assert np.allclose(batch["region_motif"].numpy(), ref_motif, atol=1e-6)
+            assert np.array_equal(batch["exp_label"].numpy(), np.stack([it["exp_label"] for it in items]))
+            assert np.array_equal(batch["mask"].numpy(), np.stack([it["mask"] for it in items]))
+            assert np.allclose(batch["atpm"].numpy(), np.stack([it["atpm"] for it in items]))
+            nb += 1
+        assert nb == len(prod) and nb >= 2
+    # pretrain masking: Bernoulli(mask_ratio) per region
+    ds = D.RegionMotifDataset(st, num_region_per_sample=200, seed=5, mask_ratio=0.5)
+    b = next(iter(D.RegionBatchProducer(ds, 16, "cpu", seed=1)))
+    assert b["mask"].shape == (16, 200) and 0.4 < b["mask"].float().mean() < 0.6
+    # different epochs reshuffle; ranks see disjoint samples
+    p0 = D.RegionBatchProducer(ds, 4, "cpu", seed=1, rank=0, world=2)
+    p1 = D.RegionBatchProducer(ds, 4, "cpu", seed=1, rank=1, world=2)
+    assert not set(p0._order()) & set(p1._order())
+    o0 = p0._order().copy(); list(p0); assert not np.array_equal(o0, p0._order())
