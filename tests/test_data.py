@@ -76,3 +76,25 @@ def test_batch_producer_matches_per_item_stacking():
     p1 = D.RegionBatchProducer(ds, 4, "cpu", seed=1, rank=1, world=2)
     assert not set(p0._order()) & set(p1._order())
     o0 = p0._order().copy(); list(p0); assert not np.array_equal(o0, p0._order())
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_producer_feeds_the_model_on_the_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd.config import build_model, region_model_yaml
+    st = D.make_synthetic_store(num_peaks=3000, celltypes=("a",), seed=6)
+    ds = D.RegionMotifDataset(st, num_region_per_sample=200, seed=1, quantitative_atac=True)
+    prod = D.RegionBatchProducer(ds, batch_size=4, device="cuda", seed=2)
+    cpu = D.RegionBatchProducer(ds, batch_size=4, device="cpu", seed=2)
+    model = build_model(region_model_yaml("finetune", num_layers=2)).cuda().train()
+    batch, ref = next(iter(prod)), next(iter(cpu))
+    assert batch["region_motif"].is_cuda and torch.allclose(batch["region_motif"].cpu(), ref["region_motif"], atol=1e-6)
+    out = model(**model.get_input(batch))
+    pred, obs = model.before_loss(out, batch)
+    loss = model.after_loss(model.loss(pred, obs))
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters())
