@@ -310,8 +310,14 @@ __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int EPI>
+// RB1 = 16-row blocks of each wave's SECOND 64-row half that are real output (4: 256-row tile, 3: 224-row tile).
+// The 224-row tile exists for tile quantisation only: M = 51 456, N = 768 is 603 tiles of 256 rows = 2.36 rounds on
+// 256 CUs -> 3 rounds, but 690 tiles of 224 rows = 2.70 -> 3 rounds of 7/8 the length (-12.5 %).  Staging, LDS
+// layout and phases are unchanged (the 16 unused rows per wave-row are staged from the neighbouring rows and ignored);
+// phases P3 / P4 issue 12 instead of 16 MFMAs and the epilogue skips the last row block.
+template <int EPI, int RB1>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
+    constexpr int BMv = 128 + 32 * RB1, HW = BMv / 2;          // tile rows, rows per wave-row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
     const int tiles_n = (p.N + 255) >> 8;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int m0 = tm << 8, n0 = tn << 8;
+    const int m0 = tm * BMv, n0 = tn << 8;
     const int nk = p.K >> 6;
     const int nq = nk << 2;   // number of half-tiles
 
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
                 const int h = (j == 3);
                 row = ((hr >> 6) << 7) + h * 64 + (hr & 63);
                 row0 = ((hr0 >> 6) << 7) + h * 64 + (hr0 & 63);
-                const int g = min(m0 + row, p.M - 1);
+                const int g = min(m0 + (hr >> 6) * HW + h * 64 + (hr & 63), p.M - 1);
                 src[j][jj] = reinterpret_cast<const char*>(p.A + (size_t)g * p.lda) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
                 dst[j][jj] = row0 * 128;
             } else {
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)      \
         FB[nt][ks] = *reinterpret_cast<const bf16x8*>(buf + b_base + ((NH)*32 + nt * 16) * 128 + foff[ks]);
 #define G2_MMA(MH, NH, FB)                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mt = 0; mt < ((MH) ? RB1 : 4); ++mt) \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
             acc[(MH)*4 + mt][(NH)*2 + nt] =                                                                \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt][ks], fa[mt][ks], acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
@@ -423,10 +429,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
 #undef G2_LOAD_B
 #undef G2_MMA
 
-    const int em = m0 + wm * 128 + (lane & 15);
+    const int em = m0 + wm * HW + (lane & 15);
     const int en = n0 + wn * 64 + (lane >> 4) * 4;
     epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), em, en, tm * 4 + wm * 2);
-    epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[4]), em + 64, en, tm * 4 + wm * 2 + 1);
+    epilogue_tiles<EPI, RB1, 4>(p, *reinterpret_cast<f32x4(*)[RB1][4]>(&acc[4]), em + 64, en, tm * 4 + wm * 2 + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,9 +469,9 @@ __device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
     return (u32x2){pack2bf(a, b), pack2bf(c, d)};
 }
 
-template <int EPI>
-struct EpiStores {   // buffer-store instructions per wave and output tile (lower bound used in the counted waits)
-    static constexpr int value = (EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 32 : 16;
+template <int EPI, int RB1>
+struct EpiStores {   // buffer-store instructions per wave and output tile (EXACT: used in the counted waits)
+    static constexpr int value = ((EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 4 : 2) * (4 + RB1);
 };
 
 // wait until at most 2*halftiles (+ EXTRA) vector-memory operations of this wave are outstanding
@@ -510,7 +516,7 @@ __device__ __forceinline__ void stage_w128x2_r128x2(unsigned wa, unsigned ra, u3
 // pieces on 16 different rows per instruction, which measured store-ISSUE bound (the epilogue ran no faster when
 // it was overlapped with the next tile's MFMAs).  XOR swizzle of the 16-B chunk with (row & 7) keeps the LDS
 // writes at most 2-way conflicted.  m0w / n0w: first row / column of the wave's block.
-template <int EPI>
+template <int EPI, int RB1>
 __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4], int m0w, int n0w, int prow,
                                            u32x4 rs0, u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage) {
     const int lane = threadIdx.x & 63;
@@ -556,7 +562,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                     rv[a][b] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + b * 16, p.N - 4));
             }
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < (half ? RB1 : 4); ++a)
 #pragma unroll
                 for (int bp = 0; bp < 2; ++bp) {
                     u32x4 qv[2], dd[2];
@@ -599,7 +605,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                                                                min(en + b * 16, p.N - 4));
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
+        for (int a = 0; a < (half ? RB1 : 4); ++a) {
             const int ab = half * 4 + a;
             const bool mok = (em + ab * 16) < p.M;
             // bf16 output(s): 16 rows x 64 columns (128 B per row) per stage pass
@@ -661,10 +667,11 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
     }
 }
 
-template <int EPI>
+template <int EPI, int RB1>      // RB1: see gemm_tn256_kernel (4 = 256-row tiles, 3 = 224-row tiles)
 __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int E = EpiStores<EPI>::value;
+    constexpr int E = EpiStores<EPI, RB1>::value;
+    constexpr int BMv = 128 + 32 * RB1, HW = BMv / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     const u32x4 rs0 = make_rsrc(p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
     const u32x4 rs1 = make_rsrc(p.out1 ? p.out1 : p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
     const u32x4 rsc = make_rsrc(p.colsum ? (const void*)p.colsum : (const void*)p.out0,
-                                p.colsum ? (unsigned)((size_t)((p.M + 255) / 256) * 4 * p.N * 4) : 0u);
+                                p.colsum ? (unsigned)((size_t)((p.M + BMv - 1) / BMv) * 4 * p.N * 4) : 0u);
 
     // ---- staging offsets (bytes from p.A / p.B) of the current and the next output tile ----
     unsigned cur[4][2], nxt[4][2];
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
                 const int hr = (wave * 2 + jj) * 8 + (lane >> 3);
                 if (j == 0 || j == 3) {
                     const int row = ((hr >> 6) << 7) + (j == 3) * 64 + (hr & 63);
-                    const int g = min((tm << 8) + row, p.M - 1);
+                    const int g = min(tm * BMv + (hr >> 6) * HW + (j == 3) * 64 + (hr & 63), p.M - 1);
                     o[j][jj] = (unsigned)((size_t)g * p.lda * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
                 } else {
                     const int row = ((hr >> 5) << 6) + (j - 1) * 32 + (hr & 31);
@@ -779,10 +786,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
 #define GP_RD_B(FB, NH, ks, addr) GP_RD(FB[0][ks], addr, (NH)*4096); GP_RD(FB[1][ks], addr, (NH)*4096 + 2048);
     // the two MFMAs of row-block mt, k-step ks of quadrant (MH, NH)
 #define GP_MM(MH, NH, FB, mt, ks)                                                                          \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
-        acc[(MH)*4 + mt][(NH)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
-            __builtin_bit_cast(bf16x8, FB[nt][ks]), __builtin_bit_cast(bf16x8, fa[mt][ks]),               \
-            acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);                                                       \
+    if constexpr ((MH) == 0 || (mt) < RB1) {                                                               \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
+            acc[(MH)*4 + mt][(NH)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+                __builtin_bit_cast(bf16x8, FB[nt][ks]), __builtin_bit_cast(bf16x8, fa[mt][ks]),           \
+                acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);                                                   \
+    }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);   /* keep the pair between its wait and the next one */
 #define GP_MM4(MH, NH, FB, ks) GP_MM(MH, NH, FB, 0, ks) GP_MM(MH, NH, FB, 1, ks) GP_MM(MH, NH, FB, 2, ks) GP_MM(MH, NH, FB, 3, ks)
     // counted wait of a reading phase: `win` > 0 while the needed half-tile predates the last epilogue
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
             const int lid = it * G + bslot;
             const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
             const float* bl = has_bias ? reinterpret_cast<const float*>(bias_img) + wn * 64 + (lane >> 4) * 4 : nullptr;
-            epilogue_p<EPI>(p, acc, (tm << 8) + wm * 128, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
+            epilogue_p<EPI, RB1>(p, acc, tm * BMv + wm * HW, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1201,20 +1210,6 @@ static bool use_big_tile(const GemmArgs& a) {
     return a.M >= 2048 && a.N >= 512;
 }
 
-template <int EPI>
-static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-        attr_set = true;
-    }
-    const int grid = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    hipLaunchKernelGGL(gemm_tn256_kernel<EPI>, dim3(grid), dim3(512), G2_LDS, st, a);
-    GETMI_CHECK_LAUNCH("gemm_tn256");
-    return GETMI_OK;
-}
-
 // CUs the one-workgroup-per-CU kernels (persistent GEMM, wgrad) may assume they get.  These workgroups take a
 // whole CU (148 KiB LDS, all 512 VGPRs of every SIMD), so a CU that hosts any other resident wave -- e.g. one of
 // RCCL's channel workgroups while a gradient all-reduce overlaps backward -- cannot take one, and with a grid
@@ -1239,17 +1234,53 @@ int getmi_set_cu_limit_impl(int n) {
 }
 int getmi_cu_count_impl() { return num_cu(); }
 
-template <int EPI>
+// Tile height of the 8-wave kernels for an M x N problem: 224 rows (RB1 = 3) when the rounds the CUs need, weighted by
+// the tile height, come out shorter than with 256 rows (RB1 = 4) even after charging the short tile 6 % (same
+// staging and barriers for 7/8 of the MFMAs; measured: N = 768 at M = 51 456 gains 3-6 %, N = 3072 would lose 3 %
+// although its rounds x height is 4 % smaller).  GETMI_GEMM_BM=256|224 forces one.
+static int pick_rb1(int M, int N) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("GETMI_GEMM_BM");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 256) return 4;
+    if (forced == 224) return 3;
+    const int tiles_n = (N + 255) / 256, cus = num_cu();
+    auto span = [&](int bm) {
+        const long tiles = (long)((M + bm - 1) / bm) * tiles_n;
+        return (double)((tiles + cus - 1) / cus) * bm;
+    };
+    return 1.06 * span(224) < span(256) ? 3 : 4;
+}
+
+template <int EPI, int RB1>
+static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<EPI, RB1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    constexpr int BMv = 128 + 32 * RB1;
+    const int grid = ((a.M + BMv - 1) / BMv) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_tn256_kernel<EPI, RB1>), dim3(grid), dim3(512), G2_LDS, st, a);
+    GETMI_CHECK_LAUNCH("gemm_tn256");
+    return GETMI_OK;
+}
+
+template <int EPI, int RB1>
 static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256p_kernel<EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256p_kernel<EPI, RB1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS + 1024 + 16384);
         attr_set = true;
     }
-    const int ntiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    constexpr int BMv = 128 + 32 * RB1;
+    const int ntiles = ((a.M + BMv - 1) / BMv) * ((a.N + 255) / 256);
     const int grid = ntiles < num_cu() ? ntiles : num_cu();
-    hipLaunchKernelGGL(gemm_tn256p_kernel<EPI>, dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles);
+    hipLaunchKernelGGL((gemm_tn256p_kernel<EPI, RB1>), dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles);
     GETMI_CHECK_LAUNCH("gemm_tn256p");
     return GETMI_OK;
 }
@@ -1263,15 +1294,17 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
         const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
         const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
                             (size_t)a.M * a.ldo * esz < 0xF0000000ull;
+        const bool short_tile = pick_rb1(a.M, a.N) == 3;
         if constexpr (can_persist) {
-            if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3) return launch_gemm_tn256p<EPI>(a, st);
+            if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3)
+                return short_tile ? launch_gemm_tn256p<EPI, 3>(a, st) : launch_gemm_tn256p<EPI, 4>(a, st);
         }
-        return launch_gemm_tn256<EPI>(a, st);
+        return short_tile ? launch_gemm_tn256<EPI, 3>(a, st) : launch_gemm_tn256<EPI, 4>(a, st);
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         attr_set = true;
     }
     const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
@@ -1284,7 +1317,9 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
 int getmi_gemm_tn_colsum_rows(int M, int N) {
     GemmArgs a{};
     a.M = M; a.N = N;
-    return use_big_tile(a) ? ((M + 255) / 256) * 4 : ((M + 127) / 128) * 2;
+    if (!use_big_tile(a)) return ((M + 127) / 128) * 2;
+    const int bm = pick_rb1(M, N) == 3 ? 224 : 256;
+    return ((M + bm - 1) / bm) * 4;
 }
 
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
