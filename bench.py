@@ -37,15 +37,18 @@ def synthetic_batch(B, N, seed, device):
     return {"region_motif": rm.to(device), "exp_label": exp.to(device)}
 
 
-# bench kernel group -> (primary device kernels, helper kernels launched with them), as rocprofv3 names them
+# bench kernel group -> (primary device kernels, helper kernels launched with them): name PREFIXES as rocprofv3 prints
+# them (template arguments after the first vary with the tile height)
+def _tn(*epis):
+    return [f"{k}<{e}" for e in epis for k in ("gemm_tn256p_kernel", "gemm_tn256_kernel", "gemm_tn_kernel")]
+
+
 _TRAFFIC_GROUPS = {
     "gemm_wgrad_kernel(+reduce_slabs)": (["gemm_wgrad256_kernel", "gemm_wgrad_kernel"], ["reduce_slabs_kernel"]),
-    "gemm_tn_kernel<bf16>": (["gemm_tn256p_kernel<0>", "gemm_tn256_kernel<0>", "gemm_tn_kernel<0>"], []),
-    "gemm_tn_kernel<bias_gelu>": (["gemm_tn256p_kernel<1>", "gemm_tn256_kernel<1>", "gemm_tn_kernel<1>",
-                                   "gemm_tn256p_kernel<6>", "gemm_tn256_kernel<6>", "gemm_tn_kernel<6>"], []),
-    "gemm_tn_kernel<bias_resid>": (["gemm_tn256p_kernel<2>", "gemm_tn256_kernel<2>", "gemm_tn_kernel<2>"], []),
-    "gemm_tn_kernel<dgelu>": (["gemm_tn256p_kernel<3>", "gemm_tn256_kernel<3>", "gemm_tn_kernel<3>",
-                               "gemm_tn256p_kernel<7>", "gemm_tn256_kernel<7>", "gemm_tn_kernel<7>"], []),
+    "gemm_tn_kernel<bf16>": (_tn(0), []),
+    "gemm_tn_kernel<bias_gelu>": (_tn(1, 6), []),
+    "gemm_tn_kernel<bias_resid>": (_tn(2), []),
+    "gemm_tn_kernel<dgelu>": (_tn(3, 7), []),
     "attn_bwd_kernel(+delta)": (["attn_bwd_kernel"], []),
     "attn_fwd_kernel": (["attn_fwd_kernel"], []),
 }
@@ -61,10 +64,15 @@ def pmc_traffic(group):
     with open(path) as f:
         d = json.load(f)
     prim, helpers = _TRAFFIC_GROUPS[group]
-    calls = sum(d[k]["calls"] for k in prim if k in d)
+
+    def rows(prefixes):
+        return [v for k, v in d.items() if any(k == p or k.startswith(p + ",") or k.startswith(p + ">") or
+                                               k.startswith(p + "<") for p in prefixes)]
+
+    calls = sum(v["calls"] for v in rows(prim))
     if calls == 0:
         return None
-    tot = sum(d[k]["calls"] * (d[k]["fetch_bytes"] + d[k]["write_bytes"]) for k in prim + helpers if k in d)
+    tot = sum(v["calls"] * (v["fetch_bytes"] + v["write_bytes"]) for v in rows(prim + helpers))
     return tot / calls
 
 
