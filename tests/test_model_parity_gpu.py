@@ -170,3 +170,44 @@ def test_optimizer_step_refreshes_the_bf16_weight_copies(fused):
         l2 = loss_of(fresh)
     assert l1.item() != l0.item()
     assert torch.equal(l1, l2), (l0.item(), l1.item(), l2.item())
+
+
+def test_full_size_batch_is_consistent_with_its_halves():
+    """BASELINE.json configs[1] shape (B=256, N=200 -> M = 51 456 rows: the persistent / 224-row-tile / split-slab
+    kernel paths the small golden cases never reach), size-independent property: predictions of the full batch equal
+    those of its two halves, and the gradient of the mean loss is the mean of the halves' gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd.config import build_model, region_model_yaml
+    from oracle import get_cpu as O
+    L, B, N = 2, 256, 200
+    model = build_model(region_model_yaml("finetune", num_layers=L))
+    model.load_state_dict(O.fill_state_dict("finetune", seed=5, num_layers=L))
+    model = model.cuda().eval()
+    batch = {k: v.cuda() for k, v in O.make_batch(B, N, 9).items()}
+
+    def run(sl):
+        for p in model.parameters():
+            p.grad = None
+        b = {k: v[sl] for k, v in batch.items()}
+        out = model(**model.get_input(b))
+        pred, obs = model.before_loss(out, b)
+        loss = model.after_loss(model.loss(pred, obs))
+        loss.backward()
+        return loss.detach(), out.detach(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    lf, pf, gf = run(slice(0, B))
+    la, pa, ga = run(slice(0, B // 2))
+    lb, pb, gb = run(slice(B // 2, B))
+    assert torch.isfinite(pf).all()
+    scale = pf.abs().max().item()
+    assert (pf - torch.cat([pa, pb])).abs().max().item() <= 2e-2 * scale
+    assert abs(lf.item() - 0.5 * (la.item() + lb.item())) <= 1e-3 * abs(lf.item())
+    # ... and equal those of 4 samples run alone (M = 804: the 128x128-tile kernels the golden cases pin)
+    _, p4, _ = run(slice(0, 4))
+    assert (pf[:4] - p4).abs().max().item() <= 2e-2 * scale
+    gfull, ghalf = grouped(gf), grouped({n: 0.5 * (ga[n] + gb[n]) for n in ga})
+    for n, g in gfull.items():
+        cos = F.cosine_similarity(g.flatten(), ghalf[n].flatten(), dim=0).item()
+        assert cos > 0.999, f"{n}: full batch vs halves cosine {cos}"
+        assert abs(g.norm().item() / ghalf[n].norm().item() - 1) < 2e-2, n
