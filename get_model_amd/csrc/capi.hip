@@ -12,6 +12,9 @@ int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* 
                          hipStream_t st);
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st);
 int getmi_wgrad_nsplit(int M, int N1, int N2);
+size_t getmi_wgrad_pair_workspace_bytes(int M, int N1a, int N2a, int N1b, int N2b);
+int getmi_gemm_wgrad_pair_impl(const bf16_t*, const bf16_t*, int, int, int, int, float*, int, const bf16_t*, const bf16_t*, int,
+                               int, int, int, float*, int, int, float*, size_t, hipStream_t);
 int getmi_set_cu_limit_impl(int n);
 int getmi_cu_count_impl();
 int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N2, int ldx, int ldy, float* out,
@@ -165,6 +168,16 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
                                  workspace_bytes, ST(stream));
 }
 
+size_t getmi_gemm_wgrad_pair_workspace_bytes(int M, int N1a, int N2a, int N1b, int N2b) {
+    return getmi_wgrad_pair_workspace_bytes(M, N1a, N2a, N1b, N2b);
+}
+int getmi_gemm_wgrad_pair(const void* Xa, const void* Ya, int N1a, int N2a, int ldxa, int ldya, float* outa, int accumulate_a,
+                          const void* Xb, const void* Yb, int N1b, int N2b, int ldxb, int ldyb, float* outb, int accumulate_b,
+                          int M, void* workspace, size_t workspace_bytes, void* stream) {
+    return getmi_gemm_wgrad_pair_impl(BF(Xa), BF(Ya), N1a, N2a, ldxa, ldya, outa, accumulate_a, BF(Xb), BF(Yb), N1b, N2b, ldxb,
+                                      ldyb, outb, accumulate_b, M, reinterpret_cast<float*>(workspace), workspace_bytes,
+                                      ST(stream));
+}
 int getmi_set_cu_limit(int n) { return getmi_set_cu_limit_impl(n); }
 int getmi_cu_count(void) { return getmi_cu_count_impl(); }
 

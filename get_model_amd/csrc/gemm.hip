@@ -889,6 +889,13 @@ struct WgradArgs {
     int M, N1, N2, ldx, ldy;
     float* slabs;      // [nsplit][N1][N2]
     int steps_per_split;
+    // optional second problem over the SAME rows (gemm_wgrad256_kernel only): blocks >= blocks_a work on it.  Two
+    // weight gradients that are each too small to give every CU a long K range (proj: 9 tiles) share one launch.
+    const bf16_t* Xb;
+    const bf16_t* Yb;
+    int N1b, N2b, ldxb, ldyb;
+    float* slabsb;
+    int blocks_a;      // 0: single problem
 };
 
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
@@ -1023,16 +1030,26 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(WgradArgs p) {
 //     Y-half h : columns {wc*64  + h*32 + 0..31 | wc = 0..3} stored at local column wc*32 + c
 // LDS: 2 buffers x (X0 | X1 | Y0 | Y1) x 16 KiB = 128 KiB, one workgroup per CU.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
+    // problem of this block (workgroup-uniform scalar selects)
+    const bool second = pa.blocks_a > 0 && (int)blockIdx.x >= pa.blocks_a;
+    struct { const bf16_t* X; const bf16_t* Y; int M, N1, N2, ldx, ldy; float* slabs; int steps_per_split; } p;
+    p.X = second ? pa.Xb : pa.X; p.Y = second ? pa.Yb : pa.Y; p.M = pa.M;
+    p.N1 = second ? pa.N1b : pa.N1; p.N2 = second ? pa.N2b : pa.N2;
+    p.ldx = second ? pa.ldxb : pa.ldx; p.ldy = second ? pa.ldyb : pa.ldy;
+    p.slabs = second ? pa.slabsb : pa.slabs; p.steps_per_split = pa.steps_per_split;
+    const int bid = second ? (int)blockIdx.x - pa.blocks_a : (int)blockIdx.x;
+    const int nblk = pa.blocks_a > 0 ? (second ? (int)gridDim.x - pa.blocks_a : pa.blocks_a) : (int)gridDim.x;
+
     // XCD-aware order: the tiles of one M-split (same X/Y rows) get consecutive logical ids = one XCD's L2
     const int tiles2 = p.N2 >> 8;
     const int ntile = (p.N1 >> 8) * tiles2;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = xcd_remap(bid, nblk);
     const int split = lid / ntile;
     const int tile = lid - split * ntile;
     const int t1 = tile / tiles2, t2 = tile - t1 * tiles2;
@@ -1399,7 +1416,7 @@ int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N
                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
         attr_set = true;
     }
-    WgradArgs a;
+    WgradArgs a{};
     a.X = X; a.Y = Y; a.M = M; a.N1 = N1; a.N2 = N2; a.ldx = ldx; a.ldy = ldy; a.slabs = slabs;
     const int nk = (M + BK - 1) / BK;
     a.steps_per_split = (nk + nsplit - 1) / nsplit;
@@ -1420,6 +1437,66 @@ int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N
     int rgrid = (int)((n / 4 + 255) / 256);
     if (rgrid > 2048) rgrid = 2048;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rgrid), dim3(256), 0, st, slabs, out, n, nsplit, accumulate);
+    GETMI_CHECK_LAUNCH("reduce_slabs");
+    return GETMI_OK;
+}
+
+// ---- two weight gradients over the same rows in ONE launch (both on the 256x256 kernel) -----------------------
+static int wgrad_pair_nsplit(int M, int ta, int tb) {
+    const int nk = (M + BK - 1) / BK;
+    int want = num_cu() / (ta + tb);
+    if (want < 1) want = 1;
+    if (want > nk) want = nk;
+    if (want > 64) want = 64;
+    const int steps = (nk + want - 1) / want;
+    return (nk + steps - 1) / steps;
+}
+static bool wgrad_pair_ok(int M, int N1a, int N2a, int N1b, int N2b) {
+    return wgrad_big(M, N1a, N2a) && wgrad_big(M, N1b, N2b);
+}
+size_t getmi_wgrad_pair_workspace_bytes(int M, int N1a, int N2a, int N1b, int N2b) {
+    if (!wgrad_pair_ok(M, N1a, N2a, N1b, N2b))     // falls back to two launches sharing the workspace
+        return sizeof(float) * ((size_t)getmi_wgrad_nsplit(M, N1a, N2a) * N1a * N2a > (size_t)getmi_wgrad_nsplit(M, N1b, N2b) * N1b * N2b
+                                    ? (size_t)getmi_wgrad_nsplit(M, N1a, N2a) * N1a * N2a
+                                    : (size_t)getmi_wgrad_nsplit(M, N1b, N2b) * N1b * N2b);
+    const int ns = wgrad_pair_nsplit(M, (N1a / 256) * (N2a / 256), (N1b / 256) * (N2b / 256));
+    return (size_t)ns * ((size_t)N1a * N2a + (size_t)N1b * N2b) * sizeof(float);
+}
+int getmi_gemm_wgrad_pair_impl(const bf16_t* Xa, const bf16_t* Ya, int N1a, int N2a, int ldxa, int ldya, float* outa,
+                               int acca, const bf16_t* Xb, const bf16_t* Yb, int N1b, int N2b, int ldxb, int ldyb,
+                               float* outb, int accb, int M, float* slabs, size_t slab_bytes, hipStream_t st) {
+    GETMI_CHECK_ARG(slab_bytes >= getmi_wgrad_pair_workspace_bytes(M, N1a, N2a, N1b, N2b), "gemm_wgrad_pair: workspace too small");
+    if (!wgrad_pair_ok(M, N1a, N2a, N1b, N2b)) {
+        if (int rc = getmi_gemm_wgrad_impl(Xa, Ya, M, N1a, N2a, ldxa, ldya, outa, acca, slabs, slab_bytes, st)) return rc;
+        return getmi_gemm_wgrad_impl(Xb, Yb, M, N1b, N2b, ldxb, ldyb, outb, accb, slabs, slab_bytes, st);
+    }
+    GETMI_CHECK_ARG(ldxa % 8 == 0 && ldya % 8 == 0 && ldxb % 8 == 0 && ldyb % 8 == 0, "gemm_wgrad_pair: ld must be multiples of 8");
+    GETMI_CHECK_ARG(((uintptr_t)Xa % 16 == 0) && ((uintptr_t)Ya % 16 == 0) && ((uintptr_t)Xb % 16 == 0) &&
+                        ((uintptr_t)Yb % 16 == 0) && ((uintptr_t)outa % 16 == 0) && ((uintptr_t)outb % 16 == 0) &&
+                        ((uintptr_t)slabs % 16 == 0), "gemm_wgrad_pair: pointers must be 16-byte aligned");
+    const int ta = (N1a / 256) * (N2a / 256), tb = (N1b / 256) * (N2b / 256);
+    const int ns = wgrad_pair_nsplit(M, ta, tb);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wgrad256_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+        attr_set = true;
+    }
+    WgradArgs a{};
+    a.X = Xa; a.Y = Ya; a.M = M; a.N1 = N1a; a.N2 = N2a; a.ldx = ldxa; a.ldy = ldya; a.slabs = slabs;
+    a.Xb = Xb; a.Yb = Yb; a.N1b = N1b; a.N2b = N2b; a.ldxb = ldxb; a.ldyb = ldyb;
+    a.slabsb = slabs + (size_t)ns * N1a * N2a;
+    a.blocks_a = ta * ns;
+    const int nk = (M + BK - 1) / BK;
+    a.steps_per_split = (nk + ns - 1) / ns;
+    hipLaunchKernelGGL(gemm_wgrad256_kernel, dim3((ta + tb) * ns), dim3(512), G2_LDS, st, a);
+    GETMI_CHECK_LAUNCH("gemm_wgrad_pair");
+    const size_t na = (size_t)N1a * N2a, nb = (size_t)N1b * N2b;
+    int ga = (int)((na / 4 + 255) / 256), gb = (int)((nb / 4 + 255) / 256);
+    if (ga > 2048) ga = 2048;
+    if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ga), dim3(256), 0, st, a.slabs, outa, na, ns, acca);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gb), dim3(256), 0, st, a.slabsb, outb, nb, ns, accb);
     GETMI_CHECK_LAUNCH("reduce_slabs");
     return GETMI_OK;
 }

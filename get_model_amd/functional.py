@@ -301,7 +301,11 @@ class EncoderBlock(torch.autograd.Function):
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
                                                            want_dbias=True)
         # ---- attention branch ----
-        dproj_w = side.run(lambda: K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w))) if need[6] else None
+        # (attn.proj's weight gradient has 9 output tiles: it shares a launch with attn.qkv's further down)
+        pair = need[6] and need[3] and side.side is None
+        dproj_w = None
+        if need[6] and not pair:
+            dproj_w = side.run(lambda: K.gemm_wgrad(dz1, a, out=grad_buffer(proj_w)))
         da = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dz1, w_bf16_t(proj_w), da)                       # dz1 @ Wproj
         # q_bias / v_bias gradients (the K third has no bias, model/transformer.py:53) come out of the attention
@@ -311,7 +315,10 @@ class EncoderBlock(torch.autograd.Function):
             dqkv, dq_bias, dv_bias = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, want_bias=True)
         else:
             dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
-        dqkv_w = side.run(lambda: K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w))) if need[3] else None
+        if pair:
+            dproj_w, dqkv_w = K.gemm_wgrad_pair(dz1, a, dqkv, h1, out_a=grad_buffer(proj_w), out_b=grad_buffer(qkv_w))
+        else:
+            dqkv_w = side.run(lambda: K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w))) if need[3] else None
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
         up_block, up_scale = ctx.up

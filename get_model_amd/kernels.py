@@ -113,6 +113,24 @@ def gemm_wgrad(X, Y, out=None, accumulate=False):
     return out
 
 
+def gemm_wgrad_pair(Xa, Ya, Xb, Yb, out_a=None, out_b=None):
+    """(Xa^T @ Ya, Xb^T @ Yb) for operands with the same number of rows, in one launch."""
+    _chk(Xa, Ya, Xb, Yb, out_a, out_b)
+    M = Xa.shape[0]
+    assert Ya.shape[0] == M and Xb.shape[0] == M and Yb.shape[0] == M
+    N1a, N2a, N1b, N2b = Xa.shape[1], Ya.shape[1], Xb.shape[1], Yb.shape[1]
+    if out_a is None:
+        out_a = torch.empty(N1a, N2a, dtype=F32, device=Xa.device)
+    if out_b is None:
+        out_b = torch.empty(N1b, N2b, dtype=F32, device=Xa.device)
+    ws = _ws(lib.query("getmi_gemm_wgrad_pair_workspace_bytes", M, N1a, N2a, N1b, N2b), Xa.device)
+    e0 = _prof_begin()
+    lib.call("getmi_gemm_wgrad_pair", Xa, Ya, N1a, N2a, Xa.stride(0), Ya.stride(0), out_a, 0, Xb, Yb, N1b, N2b, Xb.stride(0),
+             Yb.stride(0), out_b, 0, M, ws, ws.numel())
+    _prof_end(e0, "gemm_wgrad_kernel(+reduce_slabs)", 2.0 * M * (N1a * N2a + N1b * N2b))
+    return out_a, out_b
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-6):
     """x fp32 [M,D] -> (y bf16 [M,D], mean [M], rstd [M])."""
     _chk(x, gamma, beta)

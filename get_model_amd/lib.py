@@ -47,6 +47,8 @@ _SIGNATURES = {
     "getmi_colsum_workspace_bytes": (_sz, [_i]),
     "getmi_colsum_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "getmi_adamw_step": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "getmi_gemm_wgrad_pair_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "getmi_gemm_wgrad_pair": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "getmi_set_cu_limit": (_i, [_i]),
     "getmi_cu_count": (_i, []),
 }

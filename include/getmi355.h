@@ -118,6 +118,12 @@ int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n
 size_t getmi_colsum_workspace_bytes(int N);
 int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* Two weight gradients over the SAME M rows in one launch (e.g. attn.proj and attn.qkv of one block: 9 + 27 output
+ * tiles share the CUs like one 36-tile problem); same semantics as two getmi_gemm_wgrad calls. */
+size_t getmi_gemm_wgrad_pair_workspace_bytes(int M, int N1a, int N2a, int N1b, int N2b);
+int getmi_gemm_wgrad_pair(const void* Xa, const void* Ya, int N1a, int N2a, int ldxa, int ldya, float* outa, int accumulate_a,
+                          const void* Xb, const void* Yb, int N1b, int N2b, int ldxb, int ldyb, float* outb, int accumulate_b,
+                          int M, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- sharing the GPU with communication kernels.  No counterpart in the reference (its GEMMs come from vendor
  *      libraries).  The persistent GEMM and the weight-gradient GEMM launch one workgroup per CU, each taking the

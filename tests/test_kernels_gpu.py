@@ -335,3 +335,15 @@ def test_cu_limit_shrinks_grids_without_changing_results(K):
     finally:
         lib.query("getmi_set_cu_limit", 0)
     assert lib.query("getmi_cu_count") == total
+
+
+def test_gemm_wgrad_pair_equals_two_calls(K):
+    """Two weight gradients over the same rows in one launch (big-tile path) and the two-launch fallback."""
+    for M, (N1a, N2a), (N1b, N2b) in ((4096 + 77, (256, 512), (768, 256)), (300, (128, 64), (64, 192))):
+        g = torch.Generator(device="cpu").manual_seed(M)
+        Xa, Ya = bf(torch.randn(M, N1a, generator=g).cuda()), bf(torch.randn(M, N2a, generator=g).cuda())
+        Xb, Yb = bf(torch.randn(M, N1b, generator=g).cuda()), bf(torch.randn(M, N2b, generator=g).cuda())
+        oa, ob = K.gemm_wgrad_pair(Xa, Ya, Xb, Yb)
+        ra, rb_ = Xa.float().t() @ Ya.float(), Xb.float().t() @ Yb.float()
+        close(oa, ra, 1e-4, 1e-3 * math.sqrt(M), "pair.a")
+        close(ob, rb_, 1e-4, 1e-3 * math.sqrt(M), "pair.b")

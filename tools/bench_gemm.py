@@ -38,6 +38,7 @@ timeit(lambda: K.gemm_tn(K.EPI_BF16, x3, wqkvT, oD), 2.0 * M * 3 * D * D, "qkv d
 timeit(lambda: K.gemm_tn(K.EPI_BF16, xD, wproj, oD), 2.0 * M * D * D, "proj dgrad (bf16, K=768)")
 timeit(lambda: K.gemm_wgrad(xD, xD), 2.0 * M * D * D, "wgrad proj 768x768")
 timeit(lambda: K.gemm_wgrad(x3, xD), 2.0 * M * 3 * D * D, "wgrad qkv 2304x768")
+timeit(lambda: K.gemm_wgrad_pair(xD, xD, x3, xD), 2.0 * M * 4 * D * D, "wgrad proj+qkv (one launch)")
 timeit(lambda: K.gemm_wgrad(xF, xD), 2.0 * M * F * D, "wgrad fc1 3072x768")
 timeit(lambda: K.gemm_wgrad(xD, xF), 2.0 * M * F * D, "wgrad fc2 768x3072")
 B, T, H = 256, 201, 12
