@@ -166,7 +166,8 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 float h0, h1, h2, h3, g0, g1, g2, g3;
                 gelu_pair<EPI>(v[0], h0, g0); gelu_pair<EPI>(v[1], h1, g1);
                 gelu_pair<EPI>(v[2], h2, g2); gelu_pair<EPI>(v[3], h3, g3);
-                *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(h0, h1, h2, h3);
+                if (p.out0)      // NULL: inference, only gelu(u) is wanted
+                    *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(h0, h1, h2, h3);
                 *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) = pack4bf(g0, g1, g2, g3);
             } else if (EPI == EPI_EMBED) {
                 const int b = m / p.regions_per_sample, r = m - b * p.regions_per_sample;
@@ -684,7 +685,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     const int Q = Gk << 2;                                      // half-tiles of the stream
 
     const unsigned esz = (EPI == EPI_BIAS_RESID) ? 4u : 2u;
-    const u32x4 rs0 = make_rsrc(p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
+    // (a NULL out0 -- allowed for the two-output GELU epilogues -- becomes an empty buffer: its stores are dropped by the
+    //  bounds check, the instruction count the waits rely on stays the same)
+    const u32x4 rs0 = make_rsrc(p.out0 ? p.out0 : p.out1, p.out0 ? (unsigned)((size_t)p.M * p.ldo * esz) : 0u);
     const u32x4 rs1 = make_rsrc(p.out1 ? p.out1 : p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
     const u32x4 rsc = make_rsrc(p.colsum ? (const void*)p.colsum : (const void*)p.out0,
                                 p.colsum ? (unsigned)((size_t)((p.M + BMv - 1) / BMv) * 4 * p.N * 4) : 0u);
@@ -1347,6 +1350,8 @@ int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
     GETMI_CHECK_ARG(a.lda >= a.K && a.ldb >= a.K && a.ldo >= a.N, "gemm_tn: leading dimension too small");
     GETMI_CHECK_ARG(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.B % 16 == 0) && ((uintptr_t)a.out0 % 16 == 0),
                     "gemm_tn: pointers must be 16-byte aligned");
+    GETMI_CHECK_ARG(a.out0 != nullptr || epi == EPI_BIAS_GELU || epi == EPI_BIAS_GELUG,
+                    "gemm_tn: out0 may be NULL only for the two-output GELU epilogues");
     switch (epi) {
         case EPI_BF16: return launch_gemm_tn<EPI_BF16>(a, st);
         case EPI_BIAS_GELU:

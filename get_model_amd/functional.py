@@ -261,7 +261,8 @@ class EncoderBlock(torch.autograd.Function):
         # --- MLP branch ---
         h2, mean2, rstd2 = K.layernorm_fwd(x_mid, n2w.detach(), n2b.detach(), eps)
         Fh = fc1_w.shape[0]
-        u = torch.empty(M, Fh, dtype=BF16, device=dev)
+        needs_bwd = any(ctx.needs_input_grad)      # all False under no_grad / inference_mode
+        u = torch.empty(M, Fh, dtype=BF16, device=dev) if needs_bwd else None     # inference: gelu'(.) is not stored
         g = torch.empty(M, Fh, dtype=BF16, device=dev)
         # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply
         K.gemm_tn(K.EPI_BIAS_GELUG, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach())

@@ -81,7 +81,8 @@ def qkv_bias(q_bias, v_bias):
 
 def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, rows_per_sample=0, aux=None,
             mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None):
-    """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated."""
+    """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated (out0 may be None for the
+    two-output GELU epilogues: only gelu(u) is stored)."""
     _chk(A, B, out0, out1, bias, resid, rowscale, aux, mask, mask_token)
     M = A.shape[0] if M is None else M
     K = A.shape[1]
@@ -89,7 +90,8 @@ def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, ro
     assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
     ws = None if dbias is None else _ws(lib.query("getmi_gemm_tn_workspace_bytes", M, N), A.device)
     e0 = _prof_begin()
-    lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, out0.shape[-1], bias,
+    ldo = (out0 if out0 is not None else out1).shape[-1]
+    lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, ldo, bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
              regions_per_sample, dbias, ws, 0 if ws is None else ws.numel())
     _prof_end(e0, "gemm_tn_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K)

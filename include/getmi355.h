@@ -49,7 +49,8 @@ int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, 
  *   5 F32         out0(f32) = acc (+bias)                               head_mask: model.py:528
  *   6 BIAS_GELUG  out0(bf16)=gelu'(u), u=acc+bias ; out1(bf16)=gelu_erf(u)   training form of 1: saves the derivative
  *   7 DMUL        out0(bf16) = acc * aux                                autograd of :173 with aux = gelu'(u) from 6
- * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned pointers.  Unused pointers may be NULL. */
+ * K % 64 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned pointers.  Unused pointers may be NULL; for epilogues 1
+ * and 6 out0 may be NULL too (inference: only gelu(u) is stored). */
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0,
                   void* out1, int ldo, const float* bias, const float* resid, const float* rowscale,
                   int rows_per_sample, const void* aux, int ldaux, const uint8_t* mask, const float* mask_token,
