@@ -18,8 +18,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __bfloat16_as_ushort(__float2bfloat16(f)); }
+// two floats -> packed bf16 pair (RNE) in ONE v_cvt_pk_bf16_f32; converting them one at a time costs four
+// instructions per pair (two half-used v_cvt_pk + shift + or), which showed in every bf16 epilogue.
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ uint2 pack4bf(float a, float b, float c, float d) {
     return make_uint2(pack2bf(a, b), pack2bf(c, d));
