@@ -46,6 +46,17 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
     const u32x4 v = {pack2bf(a0, a1), pack2bf(a2, a3), pack2bf(a4, a5), pack2bf(a6, a7)};
     return __builtin_bit_cast(bf16x8, v);
 }
+// Row-per-lane accumulators (lane = row r of 32, half h2; registers = 4 consecutive d at 8*g4 + 4*h2 of each 32-wide
+// d block) leave a kernel as 8-byte pieces on 64 different rows per store instruction, which is store-ISSUE bound
+// (measured with s_memtime stamps: 4-7 k cycles for the dK / dV rows of one backward workgroup).  Staged through a
+// wave-private LDS block [rows][128 B] (16-B chunk index XOR (row & 7)) they leave as whole 128-byte rows instead:
+// 16 bytes per lane, 8 rows per instruction.
+__device__ __forceinline__ void stage_row_piece(char* blk, int row, int d0, uint2 v) {
+    *reinterpret_cast<uint2*>(blk + row * 128 + ((((d0 >> 3) ^ (row & 7)) << 4) | ((d0 & 4) << 1))) = v;
+}
+__device__ __forceinline__ uint4 stage_row_chunk(const char* blk, int row, int chunk) {
+    return *reinterpret_cast<const uint4*>(blk + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -171,20 +182,47 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
 
     l += __shfl_xor(l, 32, 64);
     const int q = q0 + r;
-    if (q < T) {
+    // (the chunk loop ended with a barrier: the K/V buffers are free; each wave takes 4 KiB of them as its stage)
+    if (q0 < T) {
         const float inv = 1.0f / l;
-        bf16_t* orow = p.out + ((size_t)b * T + q) * (H * HD) + h * HD;
+        char* blk = smem + wave * 4096;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = db * 32 + 8 * g4 + 4 * h2;
-                *reinterpret_cast<uint2*>(orow + d0) = pack4bf(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
-                                                               o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+                stage_row_piece(blk, r, d0, pack4bf(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
+                                                    o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
             }
-        if (h2 == 0) p.lse[((size_t)b * H + h) * T + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+        if (h2 == 0 && q < T) p.lse[((size_t)b * H + h) * T + q] = (m + __builtin_amdgcn_logf(l)) * LN2;
+        // (same wave wrote and reads: DS operations of a wave execute in order)
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = stage_row_chunk(blk, row, ch);
+            if (q0 + row < T)
+                *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8) = v;
+        }
     }
 }
+
+// Diagnostic build only (-DGETMI_ATTN_STAMPS, tools/attn_stamps.py): s_memtime stamps of every wave of the backward
+// kernel at its phase boundaries, read back through getmi_debug_attn_stamps.  The product library has none of this.
+#ifdef GETMI_ATTN_STAMPS
+#define STAMP_WG 4096
+__device__ unsigned long long g_attn_stamps[STAMP_WG * 8 * 32];
+#define STAMP(i)                                                                                          \
+    do {                                                                                                  \
+        if (lane == 0 && blockIdx.x < STAMP_WG)                                                           \
+            g_attn_stamps[((size_t)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+extern "C" int getmi_debug_attn_stamps(void* dst, size_t bytes) {
+    if (bytes > sizeof(g_attn_stamps)) bytes = sizeof(g_attn_stamps);
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 struct AttnBwdArgs {
     const bf16_t* qkv;
@@ -231,6 +269,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     const float c2 = p.scale * LOG2E;
     const float inv_scale = 1.0f / p.scale;
     const int nks = min(8, (T - key_base + 31) >> 5);     // 32-key groups of this workgroup that hold a valid key
+    STAMP(0);
 
     // ---- K image: 256 rows = 32 wave-instructions, 4 per wave (rows past T clamp to T-1: finite, and their dS is 0) ----
 #pragma unroll
@@ -260,6 +299,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     f32x4 dqs = {0.f, 0.f, 0.f, 0.f};   // running sum over queries of this wave's dQ tiles (q_bias gradient)
     float* stf = reinterpret_cast<float*>(smem + BW_ST);
     int dsbuf = 0;
+    STAMP(1);
 
     for (int qc = 0; qc < T; qc += 256) {
         if (qc) __syncthreads();   // every wave has left the previous chunk's images
@@ -298,7 +338,9 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             if (tid & 1) stf[tid >> 1] = (qi < T) ? -lse[qi] * inv_scale : -INFINITY;
             else stf[256 + (tid >> 1)] = -acc;
         }
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
         if (qc == 0) {
             const int krow = wave * 32 + r;
 #pragma unroll
@@ -313,6 +355,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                                     lds_tr16a(smem + BW_KIMG + off128(klo + 4, kcol)));
             }
         }
+        STAMP(4);
         const int nsl = nrow >> 5;
         for (int sl = 0; sl < nsl; ++sl) {
             const char* qimg = smem + BW_QIMG + sl * 4096;
@@ -384,9 +427,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                         dk[db] = MFMA32(qt, dsf[ss], dk[db]);
                     }
             }
+            if (qc == 0 && sl < 7) STAMP(5 + 3 * sl);
             // one barrier per slice: the dS image is double buffered, so a wave that runs ahead into slice sl+1
             // writes the other buffer, and cannot reach slice sl+2 before everyone has passed slice sl+1's barrier.
             __syncthreads();
+            if (qc == 0 && sl < 7) STAMP(6 + 3 * sl);
             // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys ----
             {
                 const int qh = wave & 1, dblk = wave >> 1;
@@ -419,10 +464,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                     }
                 }
             }
+            if (qc == 0 && sl < 7) STAMP(7 + 3 * sl);
             dsbuf ^= 1;
         }
     }
 
+    STAMP(26);
     if (p.bias_partial != nullptr) {
         // ---- q_bias / v_bias gradients = column sums of dQ / dV over all tokens: this workgroup's share, from the
         //      fp32 accumulators (the q_bias gradient is a cancellation sum; summing the bf16-rounded dqkv loses it).
@@ -474,21 +521,32 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             p.bias_partial[((size_t)(tid >> 6) * R + (size_t)b * nkb + kbi) * (H * HD) + h * HD + d] = v;
         }
     }
-    if (mykey < T) {
-        bf16_t* krow = p.dqkv + ((size_t)b * T + mykey) * rs + H * HD + h * HD;
-        bf16_t* vrow = krow + H * HD;
+    STAMP(27);
+    if (wave_active) {
+        // every wave is past the last slice's barrier, after which nobody reads the K / Q / dO images: wave w takes
+        // 8 KiB of them as its stage: rows 0-31 = dK of its keys, rows 32-63 = dV
+        char* blk = smem + BW_KIMG + wave * 8192;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = db * 32 + 8 * g4 + 4 * h2;
-                *reinterpret_cast<uint2*>(krow + d0) =
-                    pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale, dk[db][4 * g4 + 2] * p.scale,
-                            dk[db][4 * g4 + 3] * p.scale);
-                *reinterpret_cast<uint2*>(vrow + d0) =
-                    pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2], dv[db][4 * g4 + 3]);
+                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale,
+                                                    dk[db][4 * g4 + 2] * p.scale, dk[db][4 * g4 + 3] * p.scale));
+                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2],
+                                                         dv[db][4 * g4 + 3]));
             }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = stage_row_chunk(blk, row, ch);
+            const int key = key_base + wave * 32 + (row & 31);
+            if (key < T)
+                *reinterpret_cast<uint4*>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * H * HD + h * HD +
+                                          ch * 8) = v;
+        }
     }
+    STAMP(28);
 }
 
 // dqkv[b,t,0,h,:] = bf16(sum over key blocks of dq_acc[kb][b,t,h,:])   (long-context path only)
