@@ -311,6 +311,13 @@ __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// (defined with the persistent kernel below; the one-tile kernel uses them for its fp32 residual epilogue)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes);
+template <int EPI, int RB1>
+__device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4], int m0w, int n0w, int prow, u32x4 rs0,
+                                           u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage);
+
 // RB1 = 16-row blocks of each wave's SECOND 64-row half that are real output (4: 256-row tile, 3: 224-row tile).
 // The 224-row tile exists for tile quantisation only: M = 51 456, N = 768 is 603 tiles of 256 rows = 2.36 rounds on
 // 256 CUs -> 3 rounds, but 690 tiles of 224 rows = 2.70 -> 3 rounds of 7/8 the length (-12.5 %).  Staging, LDS
@@ -430,6 +437,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
 #undef G2_LOAD_B
 #undef G2_MMA
 
+    if constexpr (EPI == EPI_BIAS_RESID) {
+        // fp32 residual epilogue through the wave-private LDS stage of epilogue_p: every store instruction writes whole
+        // 128-byte lines (8 rows x 128 B) instead of 64-byte pieces on 16 rows.  The operand ring is free here: every
+        // LDS-DMA has landed (the last phases waited vmcnt(0)) and the barrier below orders all fragment reads first.
+        __syncthreads();
+        float* bias_img = reinterpret_cast<float*>(smem);
+        if (p.bias != nullptr && tid < 64)
+            *reinterpret_cast<float4*>(bias_img + tid * 4) = *reinterpret_cast<const float4*>(p.bias + min(n0 + tid * 4, p.N - 4));
+        __syncthreads();
+        const u32x4 rs0 = make_rsrc(p.out0, (unsigned)((size_t)p.M * p.ldo * 4));
+        const float* bl = p.bias != nullptr ? bias_img + wn * 64 + (lane >> 4) * 4 : nullptr;
+        epilogue_p<EPI, RB1>(p, acc, m0 + wm * HW, n0 + wn * 64, tm * 4 + wm * 2, rs0, rs0, rs0, bl, smem + 1024 + wave * 2048);
+        return;
+    }
     const int em = m0 + wm * HW + (lane & 15);
     const int en = n0 + wn * 64 + (lane >> 4) * 4;
     epilogue_tiles<EPI, 4, 4>(p, *reinterpret_cast<f32x4(*)[4][4]>(&acc[0]), em, en, tm * 4 + wm * 2);
@@ -552,15 +573,24 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
         // fp32 output: a row block of 16 rows x 32 columns (128 B per row) per stage pass
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            float4 rv[4][4];
+            // the residual is read in the layout the stage hands back (8 rows x 128 B per instruction, 16 B per lane): whole
+            // lines, like the stores, and it is added after the transposition.  rv[a][bp][ps]: row 16a + 8ps + rrow,
+            // columns 32bp + 4rch .. +3 of the wave's block.  (Issuing the loads in groups of two row blocks ahead of
+            // the previous group's stores measured slower: 122.5 vs 120.5 us for attn.proj.)
+            float4 rv[4][2][2];
             float sc[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const int m = min(em + (half * 4 + a) * 16, p.M - 1);
-                sc[a] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+                const int ms = min(em + (half * 4 + a) * 16, p.M - 1);
+                sc[a] = p.rowscale ? p.rowscale[ms / p.rows_per_sample] : 1.0f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    rv[a][b] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + b * 16, p.N - 4));
+                for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) {
+                        const int m = min(m0w + (half * 4 + a) * 16 + ps * 8 + rrow, p.M - 1);
+                        rv[a][bp][ps] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo +
+                                                                         min(n0w + bp * 32 + rch * 4, p.N - 4));
+                    }
             }
 #pragma unroll
             for (int a = 0; a < (half ? RB1 : 4); ++a)
@@ -571,10 +601,9 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                     for (int bb = 0; bb < 2; ++bb) {
                         const int b = bp * 2 + bb;
                         const f32x4 v = acc[half * 4 + a][b];
-                        const float4 q = rv[a][b], bi = bv[b];
+                        const float4 bi = bv[b];
                         const float s_ = sc[a];
-                        const f32x4 o = {q.x + s_ * (v[0] + bi.x), q.y + s_ * (v[1] + bi.y), q.z + s_ * (v[2] + bi.z),
-                                         q.w + s_ * (v[3] + bi.w)};
+                        const f32x4 o = {s_ * (v[0] + bi.x), s_ * (v[1] + bi.y), s_ * (v[2] + bi.z), s_ * (v[3] + bi.w)};
                         qv[bb] = __builtin_bit_cast(u32x4, o);
                     }
                     // 16-B chunk index of (bb, c) is bb*4 + c
@@ -584,7 +613,10 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                         const int row = ps * 8 + rrow;
                         const int m = m0w + (half * 4 + a) * 16 + row, n = n0w + bp * 32 + rch * 4;
                         const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 4) : OOB_OFF;
-                        st_b128(dd[ps], off, rs0);
+                        const f32x4 t = __builtin_bit_cast(f32x4, dd[ps]);
+                        const float4 q = rv[a][bp][ps];
+                        const f32x4 o = {q.x + t[0], q.y + t[1], q.z + t[2], q.w + t[3]};
+                        st_b128(__builtin_bit_cast(u32x4, o), off, rs0);
                     }
                 }
         }
@@ -1193,6 +1225,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
     float* out = p.slabs + (size_t)split * p.N1 * p.N2;
     const int e1 = n1_0 + wr * 128 + (lane & 15);
     const int e2 = n2_0 + wc * 64 + (lane >> 4) * 4;
+    // (staging the tile through LDS for whole-line stores, as the gemm_tn epilogues do, measured no difference here:
+    //  one epilogue per ~200-us workgroup)
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
