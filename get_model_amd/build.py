@@ -17,6 +17,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgetmi355.so")
 SOURCES = ["error.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-ffp-contract=fast"]
+FLAGS += os.environ.get("GETMI_EXTRA_HIPCC_FLAGS", "").split()      # experiments (A/B builds via GETMI_LIB)
 
 
 def _stamp(src):

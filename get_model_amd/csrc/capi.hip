@@ -5,7 +5,7 @@
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; int M, N, K, lda, ldb; void* out0; void* out1; int ldo; const float* bias;
     const float* resid; const float* rowscale; int rows_per_sample; const bf16_t* aux; int ldaux;
-    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum;
+    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0;
 };
 int getmi_gemm_tn_colsum_rows(int M, int N);
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
@@ -73,7 +73,7 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
                   const void* aux, int ldaux, const uint8_t* mask, const float* mask_token, int regions_per_sample,
                   float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
-               mask, mask_token, regions_per_sample, nullptr};
+               mask, mask_token, regions_per_sample, nullptr, 0};
     if (dbias) {
         GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
         GETMI_CHECK_ARG(workspace && workspace_bytes >= getmi_gemm_tn_workspace_bytes(M, N) &&

@@ -59,6 +59,7 @@ struct GemmArgs {
     const float* mask_token;
     int regions_per_sample;
     float* colsum;   // EPI_DGELU only: partial column sums of out0 (fp32, pre-rounding) [rows][N]; may be null
+    int row0;        // first row of this launch within the caller's problem (split launches; only the row scale uses it)
 };
 
 #define BM 128
@@ -86,7 +87,7 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = min(em + mt * MS, p.M - 1);
-            sc[mt] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.0f;
+            sc[mt] = p.rowscale ? p.rowscale[(m + p.row0) / p.rows_per_sample] : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 rv[mt][nt] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo + min(en + nt * NS, p.N - 4));
@@ -582,7 +583,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int ms = min(em + (half * 4 + a) * 16, p.M - 1);
-                sc[a] = p.rowscale ? p.rowscale[ms / p.rows_per_sample] : 1.0f;
+                sc[a] = p.rowscale ? p.rowscale[(ms + p.row0) / p.rows_per_sample] : 1.0f;
 #pragma unroll
                 for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
@@ -1339,21 +1340,92 @@ static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
     return GETMI_OK;
 }
 
+// ---- tile-height plan ------------------------------------------------------------------------------------------
+// Relative time of one round of tiles of height 256 / 224 / 192 rows (RB1 = 4 / 3 / 2): a K-tile costs the same staging,
+// barriers and fragment reads at every height and 64 / 56 / 48 MFMAs per wave (measured for 224; linear model for 192).
+static double tile_cost(int rb1) { return rb1 == 4 ? 1.0 : rb1 == 3 ? 0.9275 : 0.87; }
+struct RowSeg { int rows, rb1; };
+// A problem whose tile count is not close to a multiple of the CU count loses a partial round.  For the epilogues that
+// only index by row (plain bf16, fp32 residual) the rows may be cut in two launches with different tile heights so that
+// each launch is close to whole rounds: M = 51 456, N = 768 is 3 rounds of 224-row tiles, or ONE round of 224 (85 row
+// blocks) + two of 192.  GETMI_GEMM_MIXED=0 turns this off.
+static int plan_rows(int M, int N, bool may_split, RowSeg seg[2]) {
+    static int mixed = -1;
+    if (mixed < 0) {
+        const char* e = getenv("GETMI_GEMM_MIXED");
+        mixed = e ? atoi(e) : 1;
+    }
+    const int tiles_n = (N + 255) / 256, cus = num_cu();
+    const int rb_u = pick_rb1(M, N), h_u = 128 + 32 * rb_u;
+    const long tiles_u = (long)((M + h_u - 1) / h_u) * tiles_n;
+    double best = (double)((tiles_u + cus - 1) / cus) * tile_cost(rb_u);
+    seg[0] = RowSeg{M, rb_u};
+    int nseg = 1;
+    if (!may_split || !mixed || tiles_u <= cus) return nseg;
+    static const int pairs[3][2] = {{4, 3}, {4, 2}, {3, 2}};
+    for (int pi = 0; pi < 3; ++pi) {
+        const int rb1 = pairs[pi][0], rb2 = pairs[pi][1], h1 = 128 + 32 * rb1, h2 = 128 + 32 * rb2;
+        for (int r1 = 1; r1 <= 16; ++r1) {
+            const long nb1 = (long)r1 * cus / tiles_n;          // whole row blocks of r1 full rounds
+            const long rows1 = nb1 * h1;
+            if (nb1 == 0 || rows1 >= M) break;
+            const long nb2 = (M - rows1 + h2 - 1) / h2;
+            const long r2 = (nb2 * tiles_n + cus - 1) / cus;
+            // + the second launch: the drain of one grid and the fill of the next cost ~4 us, a fifth of a K = 768 round.
+            // Measured at M = 51 456: N = 2304 (1 round of 256 + 7 of 224 instead of 8 of 256) 236 -> 228 us; N = 768
+            // (1 of 224 + 2 of 192 instead of 3 of 224) +1 ... +5 %, which this charge excludes.
+            const double c = r1 * tile_cost(rb1) + r2 * tile_cost(rb2) + 0.2;
+            if (c < best - 1e-9) {
+                best = c;
+                seg[0] = RowSeg{(int)rows1, rb1};
+                seg[1] = RowSeg{(int)(M - rows1), rb2};
+                nseg = 2;
+            }
+        }
+    }
+    return nseg;
+}
+
+template <int EPI, int RB1>
+static int launch_gemm_big(const GemmArgs& a, hipStream_t st) {
+    // BIAS_RESID stays on the one-tile-per-workgroup kernel: its epilogue LOADS the fp32 residual (ordinary loads
+    // force a vmcnt(0) drain) and measured 302 vs 278 us (fc2) persistent vs not.
+    constexpr bool can_persist = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu);
+    const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
+    const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
+                        (size_t)a.M * a.ldo * esz < 0xF0000000ull;
+    if constexpr (can_persist) {
+        if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3) return launch_gemm_tn256p<EPI, RB1>(a, st);
+    }
+    return launch_gemm_tn256<EPI, RB1>(a, st);
+}
+
 template <int EPI>
 static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
     if (use_big_tile(a)) {
-        // BIAS_RESID stays on the one-tile-per-workgroup kernel: its epilogue LOADS the fp32 residual (ordinary loads
-        // force a vmcnt(0) drain) and measured 302 vs 278 us (fc2) persistent vs not.
-        constexpr bool can_persist = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu);
-        const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
-        const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
-                            (size_t)a.M * a.ldo * esz < 0xF0000000ull;
-        const bool short_tile = pick_rb1(a.M, a.N) == 3;
-        if constexpr (can_persist) {
-            if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3)
-                return short_tile ? launch_gemm_tn256p<EPI, 3>(a, st) : launch_gemm_tn256p<EPI, 4>(a, st);
+        constexpr bool splittable = (EPI == EPI_BF16 || EPI == EPI_BIAS_RESID);
+        RowSeg seg[2];
+        const int nseg = plan_rows(a.M, a.N, splittable, seg);
+        int row0 = 0;
+        for (int i = 0; i < nseg; ++i) {
+            GemmArgs s = a;
+            const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
+            s.M = seg[i].rows;
+            s.row0 = a.row0 + row0;
+            s.A = a.A + (size_t)row0 * a.lda;
+            s.out0 = reinterpret_cast<char*>(a.out0) + (size_t)row0 * a.ldo * esz;
+            if (a.resid) s.resid = a.resid + (size_t)row0 * a.ldo;
+            int rc;
+            if constexpr (splittable) {
+                rc = seg[i].rb1 == 4 ? launch_gemm_big<EPI, 4>(s, st)
+                   : seg[i].rb1 == 3 ? launch_gemm_big<EPI, 3>(s, st) : launch_gemm_big<EPI, 2>(s, st);
+            } else {
+                rc = seg[i].rb1 == 4 ? launch_gemm_big<EPI, 4>(s, st) : launch_gemm_big<EPI, 3>(s, st);
+            }
+            if (rc) return rc;
+            row0 += seg[i].rows;
         }
-        return short_tile ? launch_gemm_tn256<EPI, 3>(a, st) : launch_gemm_tn256<EPI, 4>(a, st);
+        return GETMI_OK;
     }
     static bool attr_set = false;
     if (!attr_set) {

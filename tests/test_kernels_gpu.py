@@ -66,6 +66,26 @@ def test_gemm_tn_plain_asymmetric(K, M, N, K_):
     assert torch.equal(outb, bf(ref))
 
 
+@pytest.mark.parametrize("M,N,K_", [(51456, 768, 128), (51456, 2304, 64), (30000, 768, 64), (9999, 768, 64)])
+def test_gemm_tn_split_launches(K, M, N, K_):
+    """Row-split launches with mixed tile heights (plan_rows in gemm.hip): bit-exact integer product for the bf16 output,
+    and the fp32 residual epilogue with a per-sample row scale whose sample boundaries do not line up with the cut."""
+    A = ((torch.arange(M * K_, device="cuda").reshape(M, K_) * 7 + 3) % 13 - 6).float()
+    B = ((torch.arange(N * K_, device="cuda").reshape(N, K_) * 5 + 1) % 11 - 5).float()
+    ref = A @ B.t()
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    K.gemm_tn(K.EPI_BF16, bf(A), bf(B), outb)
+    assert torch.equal(outb, bf(ref))
+    T = 201 if M % 201 == 0 else 3
+    resid = rnd(M, N, seed=7)
+    bias = rnd(N, scale=0.1, seed=6)
+    rs = ((torch.arange(M // T, device="cuda") % 3).float() + 0.5)
+    x = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    K.gemm_tn(K.EPI_BIAS_RESID, bf(A), bf(B), x, bias=bias, resid=resid, rowscale=rs, rows_per_sample=T)
+    refx = resid + (ref + bias) * rs.repeat_interleave(T)[:M, None]
+    close(x, refx, 1e-5, 1e-3, "resid-split")
+
+
 @pytest.mark.parametrize("M", [402, 2211])
 def test_gemm_tn_epilogues(K, M):
     N, K_, T = 768, 768, 201
