@@ -164,16 +164,29 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
                     bf16x8 pf[2];
                     pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
                     pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+                    // V^T fragments by inline-asm transposed reads: in front of the ds_read_tr intrinsic hipcc waits
+                    // vmcnt(0) while an LDS-DMA is in flight, i.e. for the NEXT chunk's staging, which defeats the
+                    // double buffer.  This chunk's image is complete: the barrier that ended the previous iteration
+                    // came after every wave's vmcnt(0).
+                    {
+                        const unsigned vbase = lds_addr(vb);
+                        bf16x8 vf[2][2];   // [db][ss]
+                        unsigned a[8];
 #pragma unroll
-                    for (int db = 0; db < 2; ++db)
+                        for (int db = 0; db < 2; ++db)
 #pragma unroll
-                        for (int ss = 0; ss < 2; ++ss) {
-                            const int klo = sub * 32 + 16 * ss + 4 * h2 + qq;
-                            const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
-                            const bf16x8 vf = join_tr_a(lds_tr16a(vb + off128(klo, col)),
-                                                        lds_tr16a(vb + off128(klo + 8, col)));
-                            o[db] = MFMA32(vf, pf[ss], o[db]);
-                        }
+                            for (int ss = 0; ss < 2; ++ss) {
+                                const int klo = sub * 32 + 16 * ss + 4 * h2 + qq;
+                                const int col = db * 32 + 16 * (gi & 1) + 4 * pp;
+                                a[(db * 2 + ss) * 2] = vbase + off128(klo, col);
+                                a[(db * 2 + ss) * 2 + 1] = vbase + off128(klo + 8, col);
+                            }
+                        tr_read8(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], vf[0][0], vf[0][1], vf[1][0], vf[1][1]);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+#pragma unroll
+                            for (int ss = 0; ss < 2; ++ss) o[db] = MFMA32(vf[db][ss], pf[ss], o[db]);
+                    }
                 }
             }
         }

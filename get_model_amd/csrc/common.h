@@ -59,12 +59,13 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& pdf) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);   // exp(-x^2/2)
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float tail = 0.5f * poly * t * e;          // 0.5*erfc(|x|/sqrt2)
+    // ((x*x)*k so that hipcc packs both multiplies of an element pair; the 0.5 of Phi is folded into the coefficients)
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);   // exp(-x^2/2)
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    const float tail = poly * t * e;                 // 0.5*erfc(|x|/sqrt2)
     Phi = x >= 0.f ? 1.0f - tail : tail;
     pdf = 0.3989422804014327f * e;
 }
