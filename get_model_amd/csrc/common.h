@@ -119,6 +119,24 @@ __device__ __forceinline__ void tr_issue8(unsigned a0, unsigned a1, unsigned a2,
         : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
         : "memory");
 }
+// the same with a compile-time byte offset in the instruction (no address arithmetic per read)
+template <int OFF>
+__device__ __forceinline__ void tr_issue8o(const unsigned (&a)[8], tr64_t (&r)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%16\n\tds_read_b64_tr_b16 %1, %9 offset:%16\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:%16\n\tds_read_b64_tr_b16 %3, %11 offset:%16\n\t"
+        "ds_read_b64_tr_b16 %4, %12 offset:%16\n\tds_read_b64_tr_b16 %5, %13 offset:%16\n\t"
+        "ds_read_b64_tr_b16 %6, %14 offset:%16\n\tds_read_b64_tr_b16 %7, %15 offset:%16"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(OFF)
+        : "memory");
+}
+__device__ __forceinline__ void tr_wait8(tr64_t (&a)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                 :
+                 : "memory");
+}
 __device__ __forceinline__ void tr_wait16(tr64_t (&a)[8], tr64_t (&b)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),

@@ -14,6 +14,7 @@
 // K-step, XCD-aware tile order.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 enum {
     EPI_BF16 = 0,         // out0(bf16) = acc (+bias)
@@ -1118,11 +1119,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
     const bool ragged = (p.M % BK) != 0;
     const char* baseX = reinterpret_cast<const char*>(p.X);
     const char* baseY = reinterpret_cast<const char*>(p.Y);
-    // LDS offsets of the four half images inside a buffer
-    constexpr int IMG_X0 = 0, IMG_X1 = 16384, IMG_Y0 = 32768, IMG_Y1 = 49152;
+    // LDS map: the two K-tile buffers of each half image sit next to each other (X0: 0 / 16 K, X1: 32 K / 48 K, Y0: 64 K /
+    // 80 K, Y1: 96 K / 112 K), so that with one base register for X and one for Y (+64 K) every fragment read of either
+    // buffer is "precomputed lane offset + a 16-bit instruction offset": no address arithmetic in the K loop (it was
+    // one v_add per read, 54 per K-tile and wave, in a loop that already issues twice the LDS reads of gemm_tn).
+    constexpr int IMG_X0 = 0, IMG_X1 = 32768, IMG_Y0 = 65536, IMG_Y1 = 98304;
 #define W2_ISSUE(t, J)                                                                                        \
     do {                                                                                                      \
-        char* b_ = smem + (((t)&1) << 16) + ((J) == 0 ? IMG_X0 : (J) == 3 ? IMG_X1 : (J) == 1 ? IMG_Y0 : IMG_Y1); \
+        char* b_ = smem + (((t)&1) << 14) + ((J) == 0 ? IMG_X0 : (J) == 3 ? IMG_X1 : (J) == 1 ? IMG_Y0 : IMG_Y1); \
         const bool isx_ = ((J) == 0 || (J) == 3);                                                             \
         const char* base_ = isx_ ? baseX : baseY;                                                             \
         const unsigned ko_ = (unsigned)(t) * (isx_ ? kstep_x : kstep_y);                                      \
@@ -1162,11 +1166,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
     }
     bf16x8 fx[4][2], fy0[2][2], fy1[2][2];
     // (inline-asm transposed reads: see common.h).  All reads of a phase are issued, then ONE lgkmcnt wait.
-#define W2_ADDR8(BASE, OFF, I0, I1)                                                                          \
-    (BASE) + ((OFF)[0][0] ^ ((I0) << 5)), (BASE) + ((OFF)[0][1] ^ ((I0) << 5)),                              \
-    (BASE) + ((OFF)[1][0] ^ ((I0) << 5)), (BASE) + ((OFF)[1][1] ^ ((I0) << 5)),                              \
-    (BASE) + ((OFF)[0][0] ^ ((I1) << 5)), (BASE) + ((OFF)[0][1] ^ ((I1) << 5)),                              \
-    (BASE) + ((OFF)[1][0] ^ ((I1) << 5)), (BASE) + ((OFF)[1][1] ^ ((I1) << 5))
+    // Lane addresses of the eight reads of sub-tile pair (i0, i0+1): X relative to smem, Y relative to smem + 64 K.
+    const unsigned lbase = lds_addr(smem);
+    unsigned px[2][8], py[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ks = (j >> 1) & 1, h = j & 1, di = j >> 2;
+        px[0][j] = lbase + (unsigned)(xoff[ks][h] ^ ((0 + di) << 5));
+        px[1][j] = lbase + (unsigned)(xoff[ks][h] ^ ((2 + di) << 5));
+        py[j] = lbase + 65536u + (unsigned)(yoff[ks][h] ^ (di << 5));
+    }
 #define W2_JOIN_X(R, I0)                                                                                     \
     fx[I0][0] = join_tr64(R[0], R[1]); fx[I0][1] = join_tr64(R[2], R[3]);                                    \
     fx[(I0) + 1][0] = join_tr64(R[4], R[5]); fx[(I0) + 1][1] = join_tr64(R[6], R[7]);
@@ -1179,17 +1188,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
             acc[(MH)*4 + a][(NH)*2 + b] =                                                                    \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(FY[b][ks], fx[a][ks], acc[(MH)*4 + a][(NH)*2 + b], 0, 0, 0);
 
-    const unsigned lbase = lds_addr(smem);
-    for (int s = 0; s < nk; ++s) {
+    // one K-tile out of buffer PAR (compile time: it selects the instruction offsets)
+    auto ktile = [&](int s, auto par_) {
+        constexpr int PAR = decltype(par_)::value;
         const int phi = s << 2;
-        const unsigned bb = lbase + (((unsigned)s & 1u) << 16);
         tr64_t ra[8], rb[8], rc[8];
         // ---- P1: X-half0 + Y-half0 ----
         wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
         phase_barrier();
-        tr_issue8(W2_ADDR8(bb + IMG_X0, xoff, 0, 1), ra);
-        tr_issue8(W2_ADDR8(bb + IMG_X0, xoff, 2, 3), rb);
-        tr_issue8(W2_ADDR8(bb + IMG_Y0, yoff, 0, 1), rc);
+        tr_issue8o<IMG_X0 + PAR * 16384>(px[0], ra);
+        tr_issue8o<IMG_X0 + PAR * 16384>(px[1], rb);
+        tr_issue8o<IMG_Y0 - 65536 + PAR * 16384>(py, rc);
         if (s + 1 < nk) W2_ISSUE(s + 1, 3);
         tr_wait24(ra, rb, rc);
         W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2) W2_JOIN_Y(fy0, rc)
@@ -1197,18 +1206,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
         // ---- P2: Y-half1 ----
         wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
         phase_barrier();
-        {
-            bf16x8 t0, t1, t2, t3;
-            tr_read8(W2_ADDR8(bb + IMG_Y1, yoff, 0, 1), t0, t1, t2, t3);
-            fy1[0][0] = t0; fy1[0][1] = t1; fy1[1][0] = t2; fy1[1][1] = t3;
-        }
+        tr_issue8o<IMG_Y1 - 65536 + PAR * 16384>(py, rc);
+        tr_wait8(rc);
+        W2_JOIN_Y(fy1, rc)
         if (s + 2 < nk) W2_ISSUE(s + 2, 0);
         W2_MMA(0, 1, fy1)
         // ---- P3: X-half1 ----
         wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
         phase_barrier();
-        tr_issue8(W2_ADDR8(bb + IMG_X1, xoff, 0, 1), ra);
-        tr_issue8(W2_ADDR8(bb + IMG_X1, xoff, 2, 3), rb);
+        tr_issue8o<IMG_X1 + PAR * 16384>(px[0], ra);
+        tr_issue8o<IMG_X1 + PAR * 16384>(px[1], rb);
         if (s + 2 < nk) W2_ISSUE(s + 2, 1);
         tr_wait16(ra, rb);
         W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2)
@@ -1216,9 +1223,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
         // ---- P4 ----
         if (s + 2 < nk) W2_ISSUE(s + 2, 2);
         W2_MMA(1, 0, fy0)
+    };
+    for (int s = 0; s < nk; s += 2) {
+        ktile(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nk) ktile(s + 1, std::integral_constant<int, 1>{});
     }
 #undef W2_ISSUE
-#undef W2_ADDR8
 #undef W2_JOIN_X
 #undef W2_JOIN_Y
 #undef W2_MMA
