@@ -76,6 +76,10 @@ class GradBuckets:
             self.flat.append(flat)
         self.sync = True      # False: accumulate locally (micro-batches); the exchange happens in finish()
         self.overlap = True   # False: no all-reduce is launched during backward, all of them start in finish()
+        # CUs the one-workgroup-per-CU kernels may assume WHILE an all-reduce overlaps backward (0: all).  Applied from
+        # the first bucket launch of a step until finish(): forward, and backward before the first bucket, keep all CUs.
+        self.cu_limit_during_exchange = 0
+        self._cu_limited = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.zero_grad()
@@ -98,6 +102,9 @@ class GradBuckets:
         if self.world == 1:
             return
         flat = self.flat[bi]
+        if self.cu_limit_during_exchange > 0 and not self._cu_limited and self.overlap:
+            set_cu_limit(self.cu_limit_during_exchange)     # host-side grid sizes of the launches that follow
+            self._cu_limited = True
         if self._use_avg:
             self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
         elif flat.is_cuda:
@@ -156,6 +163,9 @@ class GradBuckets:
             if flat is not None:
                 flat.div_(self.world)
         self._handles = []
+        if self._cu_limited:        # the exchange is ordered before everything launched from here on
+            set_cu_limit(0)
+            self._cu_limited = False
 
     def remove(self):
         for h in self._hooks:
@@ -178,7 +188,8 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
     workgroups (the persistent GEMM / wgrad kernels take whole CUs and would otherwise run a second round for the
     displaced workgroups); and no overlap (every all-reduce starts after backward).  Each candidate runs one
     settling step and `steps` timed steps of `step_fn` (a full training step incl. buckets.finish()); ranks agree on
-    the maximum time.  Returns {"overlap": bool, "cu_limit": int, "ms": {candidate: ms_per_step}}.
+    the maximum time.  The CU limit applies only while an exchange is in flight (GradBuckets.cu_limit_during_exchange).
+    Returns {"overlap": bool, "cu_limit": int, "ms": {candidate: ms_per_step}}.
     world_size 1: nothing to tune."""
     import time
     result = {"overlap": True, "cu_limit": 0, "ms": {}}
@@ -200,7 +211,7 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
     best = None
     for overlap, limit in cands:
         buckets.overlap = overlap
-        set_cu_limit(limit)
+        buckets.cu_limit_during_exchange = limit
         step_fn()
         fence()
         t0 = time.perf_counter()
@@ -215,7 +226,7 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
         if best is None or ms < best[0]:
             best = (ms, overlap, limit)
     buckets.overlap = best[1]
-    set_cu_limit(best[2])
+    buckets.cu_limit_during_exchange = best[2]
     result["overlap"], result["cu_limit"] = best[1], best[2]
     return result
 
