@@ -1189,45 +1189,66 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(FY[b][ks], fx[a][ks], acc[(MH)*4 + a][(NH)*2 + b], 0, 0, 0);
 
     // one K-tile out of buffer PAR (compile time: it selects the instruction offsets)
-    auto ktile = [&](int s, auto par_) {
+    // STEADY (compile time): K-tiles s with s + 3 < nk -- every issue is unconditional and off the ragged last K-tile,
+    // and every wait is the full-depth vmcnt(10), so the phase heads carry no compare / branch ladders.
+#define W2_ISSUE_FAST(t, J)                                                                                   \
+    do {                                                                                                      \
+        char* b_ = smem + (((t)&1) << 14) + ((J) == 0 ? IMG_X0 : (J) == 3 ? IMG_X1 : (J) == 1 ? IMG_Y0 : IMG_Y1); \
+        const bool isx_ = ((J) == 0 || (J) == 3);                                                             \
+        const char* base_ = isx_ ? baseX : baseY;                                                             \
+        const unsigned ko_ = (unsigned)(t) * (isx_ ? kstep_x : kstep_y);                                      \
+        glds16(base_ + (size_t)(soff[J][0] + ko_), b_ + (wave * 2) * 1024);                                   \
+        glds16(base_ + (size_t)(soff[J][1] + ko_), b_ + (wave * 2 + 1) * 1024);                               \
+    } while (0)
+    auto ktile = [&](int s, auto par_, auto steady_) {
         constexpr int PAR = decltype(par_)::value;
+        constexpr bool STEADY = decltype(steady_)::value;
         const int phi = s << 2;
         tr64_t ra[8], rb[8], rc[8];
         // ---- P1: X-half0 + Y-half0 ----
-        wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
         phase_barrier();
         tr_issue8o<IMG_X0 + PAR * 16384>(px[0], ra);
         tr_issue8o<IMG_X0 + PAR * 16384>(px[1], rb);
         tr_issue8o<IMG_Y0 - 65536 + PAR * 16384>(py, rc);
-        if (s + 1 < nk) W2_ISSUE(s + 1, 3);
+        if constexpr (STEADY) W2_ISSUE_FAST(s + 1, 3); else if (s + 1 < nk) W2_ISSUE(s + 1, 3);
         tr_wait24(ra, rb, rc);
         W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2) W2_JOIN_Y(fy0, rc)
         W2_MMA(0, 0, fy0)
         // ---- P2: Y-half1 ----
-        wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
         phase_barrier();
         tr_issue8o<IMG_Y1 - 65536 + PAR * 16384>(py, rc);
         tr_wait8(rc);
         W2_JOIN_Y(fy1, rc)
-        if (s + 2 < nk) W2_ISSUE(s + 2, 0);
+        if constexpr (STEADY) W2_ISSUE_FAST(s + 2, 0); else if (s + 2 < nk) W2_ISSUE(s + 2, 0);
         W2_MMA(0, 1, fy1)
         // ---- P3: X-half1 ----
-        wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
         phase_barrier();
         tr_issue8o<IMG_X1 + PAR * 16384>(px[0], ra);
         tr_issue8o<IMG_X1 + PAR * 16384>(px[1], rb);
-        if (s + 2 < nk) W2_ISSUE(s + 2, 1);
+        if constexpr (STEADY) W2_ISSUE_FAST(s + 2, 1); else if (s + 2 < nk) W2_ISSUE(s + 2, 1);
         tr_wait16(ra, rb);
         W2_JOIN_X(ra, 0) W2_JOIN_X(rb, 2)
         W2_MMA(1, 1, fy1)
         // ---- P4 ----
-        if (s + 2 < nk) W2_ISSUE(s + 2, 2);
+        if constexpr (STEADY) W2_ISSUE_FAST(s + 2, 2); else if (s + 2 < nk) W2_ISSUE(s + 2, 2);
         W2_MMA(1, 0, fy0)
     };
-    for (int s = 0; s < nk; s += 2) {
-        ktile(s, std::integral_constant<int, 0>{});
-        if (s + 1 < nk) ktile(s + 1, std::integral_constant<int, 1>{});
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int s = 0;
+    // steady pairs: the youngest K-tile they issue is s + 3 <= nk - 2, which is never the (possibly ragged) last one
+    for (; s + 4 < nk; s += 2) {
+        ktile(s, P0{}, std::true_type{});
+        ktile(s + 1, P1{}, std::true_type{});
     }
+    for (; s < nk; s += 2) {
+        ktile(s, P0{}, std::false_type{});
+        if (s + 1 < nk) ktile(s + 1, P1{}, std::false_type{});
+    }
+#undef W2_ISSUE_FAST
 #undef W2_ISSUE
 #undef W2_JOIN_X
 #undef W2_JOIN_Y
