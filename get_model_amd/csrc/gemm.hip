@@ -838,15 +838,31 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
         else wait_halftiles_x<0>(inflight);                                                                \
     } while (0)
 
+    // issue half-tile J of stream K-tile gi when gi is known to lie in the CURRENT output tile (no select, no compare)
+#define GP_ISSUE_CUR(gi, J)                                                                                \
+    do {                                                                                                   \
+        const int gi_ = (gi);                                                                              \
+        const unsigned koff_ = (unsigned)(gi_ - tile_g0) * 128u;                                           \
+        char* b_ = smem + ((gi_ & 1) << 16);                                                               \
+        const char* base_ = ((J) == 0 || (J) == 3) ? baseA : baseB;                                        \
+        glds16(base_ + (size_t)(cur[J][0] + koff_), b_ + dst[J][0]);                                       \
+        glds16(base_ + (size_t)(cur[J][1] + koff_), b_ + dst[J][1]);                                       \
+    } while (0)
+
     int win = 0;
-    for (int g = 0; g < Gk; ++g) {
+    // One K-tile of the stream.  FAST (compile time): a K-tile in the middle of an output tile -- everything it issues
+    // (K-tiles g+1, g+2) lies in the same output tile, no store of an epilogue is still counted (win == 0) and the
+    // stream does not end within two K-tiles -- so its waits are the constant vmcnt(10) and its issues are
+    // unconditional: the phase heads carry no compare / select / branch ladders (the wgrad loop gained 6 % from this).
+    auto ktile = [&](int g, auto fast_) {
+        constexpr bool FAST = decltype(fast_)::value;
         const unsigned bo = (unsigned)(g & 1) << 16;
         const unsigned a0 = la[0] + bo, a1 = la[1] + bo, b0 = lb[0] + bo, b1 = lb[1] + bo;
         const int phi = g << 2;
         // ---- P1: A-half0 x B-half0 (12 reads) ----
-        GP_WAIT(min(phi + 6, Q - 1) - (phi + 1));
+        if constexpr (FAST) wait_halftiles_x<0>(5); else GP_WAIT(min(phi + 6, Q - 1) - (phi + 1));
         phase_barrier();
-        if (g + 1 < Gk) GP_ISSUE(g + 1, 3);
+        if constexpr (FAST) GP_ISSUE_CUR(g + 1, 3); else if (g + 1 < Gk) GP_ISSUE(g + 1, 3);
         GP_RD_B(fb0, 0, 0, b0) GP_RD_A(0, 0, a0) GP_RD_B(fb0, 0, 1, b1) GP_RD_A(0, 1, a1)
         GP_LG3(9, fb0[0][0], fb0[1][0], fa[0][0]); GP_MM(0, 0, fb0, 0, 0)
         GP_LG1(8, fa[1][0]); GP_MM(0, 0, fb0, 1, 0)
@@ -857,16 +873,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
         GP_LG1(1, fa[2][1]); GP_MM(0, 0, fb0, 2, 1)
         GP_LG1(0, fa[3][1]); GP_MM(0, 0, fb0, 3, 1)
         // ---- P2: A-half0 (in registers) x B-half1 (4 reads) ----
-        GP_WAIT(min(phi + 7, Q - 1) - (phi + 2));
+        if constexpr (FAST) wait_halftiles_x<0>(5); else GP_WAIT(min(phi + 7, Q - 1) - (phi + 2));
         phase_barrier();
-        if (g + 2 < Gk) GP_ISSUE(g + 2, 0);
+        if constexpr (FAST) GP_ISSUE_CUR(g + 2, 0); else if (g + 2 < Gk) GP_ISSUE(g + 2, 0);
         GP_RD_B(fb1, 1, 0, b0) GP_RD_B(fb1, 1, 1, b1)
         GP_LG2(2, fb1[0][0], fb1[1][0]); GP_MM4(0, 1, fb1, 0)
         GP_LG2(0, fb1[0][1], fb1[1][1]); GP_MM4(0, 1, fb1, 1)
         // ---- P3: A-half1 (8 reads) x B-half1 (in registers) ----
-        GP_WAIT(min(phi + 8, Q - 1) - (phi + 3));
+        if constexpr (FAST) wait_halftiles_x<0>(5); else GP_WAIT(min(phi + 8, Q - 1) - (phi + 3));
         phase_barrier();
-        if (g + 2 < Gk) GP_ISSUE(g + 2, 1);
+        if constexpr (FAST) GP_ISSUE_CUR(g + 2, 1); else if (g + 2 < Gk) GP_ISSUE(g + 2, 1);
         GP_RD_A(1, 0, a0) GP_RD_A(1, 1, a1)
         GP_LG1(7, fa[0][0]); GP_MM(1, 1, fb1, 0, 0)
         GP_LG1(6, fa[1][0]); GP_MM(1, 1, fb1, 1, 0)
@@ -877,10 +893,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
         GP_LG1(1, fa[2][1]); GP_MM(1, 1, fb1, 2, 1)
         GP_LG1(0, fa[3][1]); GP_MM(1, 1, fb1, 3, 1)
         // ---- P4: A-half1 x B-half0, both in registers (no barrier) ----
-        if (g + 2 < Gk) GP_ISSUE(g + 2, 2);
+        if constexpr (FAST) GP_ISSUE_CUR(g + 2, 2); else if (g + 2 < Gk) GP_ISSUE(g + 2, 2);
         GP_MM4(1, 0, fb0, 0) GP_MM4(1, 0, fb0, 1)
+    };
 
-        if (g - tile_g0 == nk - 1) {
+    for (int t = 0; t < ntl; ++t) {
+        // K-tiles of this output tile: the first two still count the previous epilogue's stores in their waits
+        // (win), the last two issue into the next output tile (or past the end of the stream): generic code
+        int k = 0;
+        const int kslow = (t == 0) ? 0 : 2;
+        for (; k < kslow && k < nk; ++k) ktile(tile_g0 + k, std::false_type{});
+        for (; k + 2 < nk; ++k) ktile(tile_g0 + k, std::true_type{});
+        for (; k < nk; ++k) ktile(tile_g0 + k, std::false_type{});
+        {
             // ---- tile finished: epilogue (its stores drain under the next tile), then switch tiles ----
             const int lid = it * G + bslot;
             const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
@@ -899,6 +924,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
             win = 5;
         }
     }
+#undef GP_ISSUE_CUR
 #undef GP_ISSUE
 #undef GP_RD
 #undef GP_LG1
