@@ -407,32 +407,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
             acc[(MH)*4 + mt][(NH)*2 + nt] =                                                                \
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[nt][ks], fa[mt][ks], acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
 
-    for (int s = 0; s < nk; ++s) {
+    // STEADY (compile time): s + 2 < nk -- full-depth waits and unconditional issues, no compare / branch ladders at the
+    // phase heads (see the persistent kernel: worth 5-15 % there).
+    auto ktile = [&](int s, auto steady_) {
+        constexpr bool STEADY = decltype(steady_)::value;
         const char* buf = smem + ((s & 1) << 16);
         const int phi = s << 2;
         // issued before phase phi: half-tiles <= min(phi+6, nq-1); needed: <= phi+1
         // ---- P1 ----
-        wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 6, nq - 1) - (phi + 1));
         phase_barrier();
         G2_LOAD_A(0)
         G2_LOAD_B(fb0, 0)
-        if (s + 1 < nk) G2_ISSUE(s + 1, 3);
+        if constexpr (STEADY) G2_ISSUE(s + 1, 3); else if (s + 1 < nk) G2_ISSUE(s + 1, 3);
         G2_MMA(0, 0, fb0)
         // ---- P2 ----
-        wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 7, nq - 1) - (phi + 2));
         phase_barrier();
         G2_LOAD_B(fb1, 1)
-        if (s + 2 < nk) G2_ISSUE(s + 2, 0);
+        if constexpr (STEADY) G2_ISSUE(s + 2, 0); else if (s + 2 < nk) G2_ISSUE(s + 2, 0);
         G2_MMA(0, 1, fb1)
         // ---- P3 ----
-        wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
+        if constexpr (STEADY) wait_vmcnt<10>(); else wait_halftiles(min(phi + 8, nq - 1) - (phi + 3));
         phase_barrier();
         G2_LOAD_A(1)
-        if (s + 2 < nk) G2_ISSUE(s + 2, 1);
+        if constexpr (STEADY) G2_ISSUE(s + 2, 1); else if (s + 2 < nk) G2_ISSUE(s + 2, 1);
         G2_MMA(1, 1, fb1)
         // ---- P4 (no new data, no barrier) ----
-        if (s + 2 < nk) G2_ISSUE(s + 2, 2);
+        if constexpr (STEADY) G2_ISSUE(s + 2, 2); else if (s + 2 < nk) G2_ISSUE(s + 2, 2);
         G2_MMA(1, 0, fb0)
+    };
+    {
+        int s = 0;
+        for (; s + 2 < nk; ++s) ktile(s, std::true_type{});
+        for (; s < nk; ++s) ktile(s, std::false_type{});
     }
 #undef G2_ISSUE
 #undef G2_LOAD_A
