@@ -1453,9 +1453,10 @@ static int plan_rows(int M, int N, bool may_split, RowSeg seg[2]) {
 
 template <int EPI, int RB1>
 static int launch_gemm_big(const GemmArgs& a, hipStream_t st) {
-    // BIAS_RESID stays on the one-tile-per-workgroup kernel: its epilogue LOADS the fp32 residual (ordinary loads
-    // force a vmcnt(0) drain) and measured 302 vs 278 us (fc2) persistent vs not.
-    constexpr bool can_persist = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu);
+    // (BIAS_RESID used to stay on the one-tile-per-workgroup kernel -- persistent measured 302 vs 278 us for fc2 when its
+    //  epilogue read the residual as 64-byte pieces behind the stores; with the row-major whole-line residual reads and
+    //  the lean K loop the persistent form is ahead: attn.proj 122 -> 116 us, fc2 257 -> 256 us.)
+    constexpr bool can_persist = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu || EPI == EPI_BIAS_RESID);
     const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
     const bool fits32 = (size_t)a.M * a.lda * 2 < 0xF0000000ull && (size_t)a.N * a.ldb * 2 < 0xF0000000ull &&
                         (size_t)a.M * a.ldo * esz < 0xF0000000ull;
