@@ -6,6 +6,11 @@ One "step" = one training step of GETRegionFinetune 12L x 768 on a synthetic bat
 get_input -> forward -> before_loss -> PoissonNLL -> backward -> bucketed gradient all-reduce (N>1) -> AdamW.
 Per-GPU batch is fixed (weak scaling): 256 samples x 200 regions (BASELINE.json configs[1]).
 Prints ONE JSON line on rank 0.
+
+The other BASELINE.json configurations (not the contract metric; each prints the same kind of line):
+    C3  --model pretrain                                   masked-region objective (mask ratio 0.5, MSE)
+    C4  --model atac --regions 2000 --batch 16             Motif->ATAC model, long context
+    C5  --model finetune --inference --batch 1024          forward only under torch.inference_mode
 """
 import argparse
 import json
@@ -24,6 +29,27 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_
 FLOP_PER_REGION_N200 = 5.358e8   # fwd+bwd algorithmic FLOPs per region at N=200 (SURVEY.md 8d / BASELINE.md 4)
 
 
+def flop_per_region(kind, N, layers, forward_only, D=768, n_feat=283, masked_frac=0.5):
+    """Algorithmic FLOPs per region (SURVEY.md 8d: 2mnk per GEMM; per layer 24 T D^2 + 4 T^2 D with T = N + 1 tokens;
+    embed 2 N 283 D; head 2 N D out, or for pre-training 2 n_masked D 283); backward = 2 x forward.
+    N=200, 12 layers, finetune: 3.572e10 per sample forward -> 5.358e8 per region fwd+bwd; N=2000: 7.33e8."""
+    T = N + 1
+    fwd = layers * (24.0 * T * D * D + 4.0 * T * T * D) + 2.0 * N * n_feat * D
+    fwd += 2.0 * masked_frac * N * D * n_feat if kind == "pretrain" else 2.0 * N * D * (2 if kind == "finetune" else 1)
+    return fwd * (1.0 if forward_only else 3.0) / N
+
+
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def synthetic_batch(B, N, seed, device):
     """motif columns U[0,1) with ~60 % zeros, ATAC column in (0,1], labels 90 % zeros else U[0,4)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -34,7 +60,8 @@ def synthetic_batch(B, N, seed, device):
     lab = torch.rand(B, N, 2, generator=g) * 4
     lz = torch.rand(B, N, 2, generator=g)
     exp = torch.where(lz < 0.9, torch.zeros_like(lab), lab)
-    return {"region_motif": rm.to(device), "exp_label": exp.to(device)}
+    mask = (torch.rand(B, N, generator=g) < 0.5).to(torch.int64)     # pretrain: Bernoulli(0.5), zarr_dataset.py:1149-1152
+    return {"region_motif": rm.to(device), "exp_label": exp.to(device), "mask": mask.to(device)}
 
 
 # bench kernel group -> (primary device kernels, helper kernels launched with them): name PREFIXES as rocprofv3 prints
@@ -58,8 +85,9 @@ def pmc_traffic(group):
     """HBM-side bytes per launch of a kernel group (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md corrections),
     from the committed rocprofv3 --pmc passes of this same workload (tools/pmc_traffic.sh -> profiles/); PMC
     counters cannot be read from inside the process, so this is None when the file or the group is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if group not in _TRAFFIC_GROUPS or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"))
+                 if os.path.exists(q)), None)
+    if group not in _TRAFFIC_GROUPS or path is None:
         return None
     with open(path) as f:
         d = json.load(f)
@@ -76,25 +104,46 @@ def pmc_traffic(group):
     return tot / calls
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores:
-    BASELINE.json configs[0] shape (B=4, N=200, 12 layers), train-mode-equivalent fwd + loss + bwd."""
+def cpu_baseline(kind="finetune", N=200, forward_only=False, budget_s=25.0):
+    """The oracle (CPU restatement of the reference path, fp32) timed on this box's host cores on a bounded sample of the
+    same workload: B=4 samples of the same model / context length (C1 shape B=4 x N=200, C4 shape
+    B=4 x N=2000), 12 layers, fwd + loss + bwd (forward only for the inference workload)."""
     from oracle import get_cpu as O
-    cores = min(16, os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host: 16 threads (OMP_NUM_THREADS there); os.cpu_count() is the machine
+    cores = min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    sd = O.fill_state_dict("finetune", seed=3, num_layers=12)
-    batch = O.make_batch(4, 200, 3)
-    O.loss_and_grads("finetune", sd, batch, num_layers=12)        # warm-up
+    B = 4
+    sd = O.fill_state_dict(kind, seed=3, num_layers=12)
+    batch = O.make_batch(B, N, 3, kind=kind)
+
+    def once():
+        if forward_only:
+            with torch.no_grad():
+                if kind == "pretrain":
+                    O.pretrain_loss(sd, batch, num_layers=12)
+                else:
+                    O.finetune_loss(sd, batch, kind=kind, num_layers=12)
+        else:
+            O.loss_and_grads(kind, sd, batch, num_layers=12)
+
+    t0 = time.time()
+    once()        # warm-up
+    warm = time.time() - t0
     times = []
-    t_end = time.time() + budget_s
+    t_end = time.time() + max(budget_s - warm, 0.0)
     while len(times) < 5 and (time.time() < t_end or not times):
         t0 = time.time()
-        O.loss_and_grads("finetune", sd, batch, num_layers=12)
+        once()
         times.append(time.time() - t0)
     best = min(times)
-    return {"value": 4 * 200 / best, "unit": "regions/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/get_cpu.py fp32 fwd+loss+bwd, GETRegionFinetune 12Lx768, B=4 x N=200, best of {len(times)} "
-                      f"steps ({best:.3f} s/step) after 1 warm-up"}
+    what = "fwd" if forward_only else "fwd+loss+bwd"
+    return {"value": B * N / best, "unit": "regions/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_string(), "host_cpus": os.cpu_count(),
+            "sample": f"oracle/get_cpu.py fp32 {what}, {MODEL_NAMES[kind]} 12Lx768, B={B} x N={N}, best of {len(times)} "
+                      f"steps ({best:.3f} s/step) after 1 warm-up, {cores} threads"}
+
+
+MODEL_NAMES = {"finetune": "GETRegionFinetune", "pretrain": "GETRegionPretrain", "atac": "GETRegionFinetuneATAC"}
 
 
 def main():
@@ -109,6 +158,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of FusedAdamW")
     ap.add_argument("--cu-limit", type=int, default=0, help="experiment: getmi_set_cu_limit before the run")
+    ap.add_argument("--model", choices=["finetune", "pretrain", "atac"], default="finetune",
+                    help="finetune = the contract workload (BASELINE configs[1]); pretrain = C3; atac = C4")
     ap.add_argument("--inference", action="store_true",
                     help="forward only, eval mode, torch.inference_mode (SURVEY 8d C5); not the contract metric")
     args = ap.parse_args()
@@ -139,10 +190,10 @@ def main():
     from get_model_amd.ddp import GradBuckets, broadcast_parameters
 
     torch.manual_seed(0)
-    model = build_model(region_model_yaml("finetune", num_layers=args.layers)).to(device)
+    model = build_model(region_model_yaml(args.model, num_layers=args.layers)).to(device)
     broadcast_parameters(model)
     model.train(not args.inference)
-    buckets = GradBuckets(model)
+    buckets = None if args.inference else GradBuckets(model)
     # AdamW as the reference configures it (config/finetune_tutorial.yaml:29-35, optim.py:44-130, run.py:477-497):
     # layer-wise parameter groups, weight decay 0.05 on >=2-D non-bias parameters; get_model_amd.optim.FusedAdamW
     # (one HIP launch, also refreshes the bf16 operand copies); --torch-adamw times torch.optim.AdamW(fused) instead
@@ -159,7 +210,8 @@ def main():
 
     def infer_step():
         with torch.inference_mode():
-            return model(**model.get_input(batch)).float().mean()
+            out = model(**model.get_input(batch))
+            return (out[0] if isinstance(out, tuple) else out).float().mean()
 
     def step():
         if args.inference:
@@ -221,26 +273,34 @@ def main():
             fl, sec, n = agg[dom]
             roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
-                    "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                    "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r0N_pmc_traffic.json)",
                     "launches": n, "avg_launch_us": sec / n * 1e6}
+        fpr = flop_per_region(args.model, N, args.layers, args.inference)
+        loss_name = "MSE" if args.model == "pretrain" else "PoissonNLL"
+        if args.inference:
+            work = (f"{MODEL_NAMES[args.model]} {args.layers}Lx768 forward only (eval mode, torch.inference_mode), "
+                    f"per-GPU batch {B} x {N} regions x 283 features")
+        else:
+            work = (f"{MODEL_NAMES[args.model]} {args.layers}Lx768 train step (fwd+{loss_name}+bwd+grad all-reduce+AdamW), "
+                    f"per-GPU batch {B} x {N} regions x 283 features")
         result = {
             "metric": ("inference" if args.inference else "train") + f" regions/sec/node, GET 12Lx768 @{N}-region ctx",
             "value": value, "unit": "regions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic region x motif tensors (SURVEY.md 8d), random-init weights",
-            "config": {"workload": f"GETRegionFinetune {args.layers}Lx768 train step (fwd+PoissonNLL+bwd+grad all-reduce+AdamW), "
-                                   f"per-GPU batch {B} x {N} regions x 283 features", "global_batch": world * B,
-                       "regions_per_sample": N, "parallelism": f"dp{world}", "grad_exchange": exchange},
+            "config": {"workload": work, "global_batch": world * B, "regions_per_sample": N, "parallelism": f"dp{world}",
+                       "grad_exchange": exchange},
             "loss": float(loss.item()),
-            "e2e_mfma_frac": value * FLOP_PER_REGION_N200 / (world * PEAK_BF16_TFLOPS * 1e12) if N == 200 and args.layers == 12 else None,
+            "flop_per_region": fpr,
+            "e2e_mfma_frac": value * fpr / (world * PEAK_BF16_TFLOPS * 1e12),
             "roofline": roof, "kernels": kernels,
         }
     if world > 1:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline(args.model, 2000 if N >= 1000 else 200, args.inference)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))

@@ -43,6 +43,7 @@ int getmi_loss_fwd_impl(int, const float*, const float*, float*, float*, size_t,
                         size_t, hipStream_t);
 int getmi_scale_by_scalar_impl(const float*, const float*, float, float*, size_t, hipStream_t);
 int getmi_gather_rows_impl(const bf16_t*, const int64_t*, bf16_t*, int, int, int, hipStream_t);
+int getmi_mask_compact_impl(const uint8_t*, int, int, int64_t*, int64_t*, int*, hipStream_t);
 size_t getmi_colsum_workspace_bytes_impl(int N);
 int getmi_colsum_bf16_impl(const bf16_t*, float*, int, int, int, int, void*, size_t, hipStream_t);
 
@@ -148,6 +149,10 @@ int getmi_scale_by_scalar(const float* in, const float* scalar_dev, float weight
 }
 int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int D, int scatter, void* stream) {
     return getmi_gather_rows_impl(BF(src), idx, BFW(dst), n, D, scatter, ST(stream));
+}
+int getmi_mask_compact(const uint8_t* mask, int B, int N, int64_t* token_rows, int64_t* region_rows, int* count,
+                       void* stream) {
+    return getmi_mask_compact_impl(mask, B, N, token_rows, region_rows, count, ST(stream));
 }
 int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
                       size_t workspace_bytes, void* stream) {

@@ -287,6 +287,48 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int64_t
     }
 }
 
+// ---- masked-row compaction (pretrain: x[:, 1:][mask], model/model.py:527,535) without a host round trip -------
+// One workgroup of 1024 threads: thread t counts the set bytes of its contiguous chunk, a block-wide exclusive scan
+// turns the counts into output offsets, and the chunk is walked again to write, in ascending order (= the row order
+// of torch boolean indexing), the token row b*(N+1)+1+r and the region row b*N+r of every masked region.
+__global__ __launch_bounds__(1024) void mask_compact_kernel(const uint8_t* __restrict__ mask, int total, int N,
+                                                            int64_t* __restrict__ token_rows,
+                                                            int64_t* __restrict__ region_rows, int* __restrict__ count) {
+    __shared__ int wave_total[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (total + 1023) / 1024;
+    const int lo = min(tid * per, total), hi = min(lo + per, total);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += mask[i] != 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_total[w];
+    int off = before + incl - c;
+    for (int i = lo; i < hi; ++i)
+        if (mask[i]) {
+            const int b = i / N, r = i - b * N;
+            token_rows[off] = (int64_t)b * (N + 1) + 1 + r;
+            region_rows[off] = i;
+            ++off;
+        }
+    if (tid == 1023) count[0] = before + incl;
+}
+
+int getmi_mask_compact_impl(const uint8_t* mask, int B, int N, int64_t* token_rows, int64_t* region_rows, int* count,
+                            hipStream_t st) {
+    GETMI_CHECK_ARG(B > 0 && N > 0 && (long long)B * N < (1ll << 31), "mask_compact: bad shape B=%d N=%d", B, N);
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(1), dim3(1024), 0, st, mask, B * N, N, token_rows, region_rows, count);
+    GETMI_CHECK_LAUNCH("mask_compact");
+    return GETMI_OK;
+}
+
 // ---- column sums of a bf16 matrix [M, N] -> partial[gridDim.y][N] (then colreduce); N % 4 == 0 ----
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, float* __restrict__ partial,
                                                           int M, int N, int ld) {

@@ -5,7 +5,7 @@ Counterpart of the reference's Lightning `strategy="ddp_find_unused_parameters_t
 are split over ranks, weights are replicated, and the only exchange step of the path is the mean of the
 gradients.  Differences by design:
   * gradients live in flat fp32 buckets laid out in REVERSE forward order (head -> block L-1 -> ... -> embed),
-    one bucket per encoder block (~28 MB at 12Lx768), so a bucket completes as soon as its block's fused
+    one bucket per encoder block (~28 MB at 12Lx768; the 30 MB cap merges only the small head / embed groups), so a bucket completes as soon as its block's fused
     backward returns and its all-reduce runs on RCCL's stream under the remaining backward;
   * `param.grad` are views into the buckets: no flatten/unflatten copies, and the optimizer reads the reduced
     gradients in place; the weight-gradient GEMMs write their result directly into the bucket slot
@@ -33,7 +33,7 @@ def _bucket_key(name):
 class GradBuckets:
     """Flat gradient buckets + async all-reduce from post-accumulate-grad hooks."""
 
-    def __init__(self, module, process_group=None, bucket_cap_mb=64.0):
+    def __init__(self, module, process_group=None, bucket_cap_mb=30.0):
         self.module = module
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -91,6 +91,12 @@ class GradBuckets:
         for b in self.buckets:
             for p in b:
                 p.grad = None
+        self._begin_step()
+
+    def _begin_step(self):
+        for b in self.buckets:
+            for p in b:
+                p._getmi_slot_taken = False         # see functional.grad_buffer
         self._remaining = [len(b) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._stray = [[] for _ in self.buckets]
@@ -120,6 +126,10 @@ class GradBuckets:
         view = self._view[p]
         g = p.grad
         bi = self._bucket_of[p]
+        p._getmi_slot_taken = False      # this backward is done with the parameter: the slot may be handed out again
+        if self._remaining[bi] <= 0 and self.sync and self._launched[bi]:
+            raise RuntimeError("ddp.GradBuckets: a gradient arrived for a bucket that was already exchanged in this step "
+                               "(a second backward without finish()? use sync=False for micro-batches)")
         if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
             # small parameters (biases, norms, tokens) and anything not written in place: gathered into the
             # bucket by ONE multi-tensor copy when the bucket completes, instead of a copy launch per parameter
@@ -166,6 +176,9 @@ class GradBuckets:
         if self._cu_limited:        # the exchange is ordered before everything launched from here on
             set_cu_limit(0)
             self._cu_limited = False
+        # the step's bookkeeping ends here, whichever zero_grad the training loop calls next (optimizer.zero_grad()
+        # leaves this object alone; with stale counters no bucket would ever be exchanged again and ranks would diverge)
+        self._begin_step()
 
     def remove(self):
         for h in self._hooks:

@@ -3,7 +3,8 @@
 Granularity follows the reference's module boundaries (`region_embed`, `encoder.blocks.i`,
 `encoder.norm`+head must stay real submodules whose outputs are autograd tensors), fused *inside* them:
 
-  RegionEmbedTokens   model/modules.py:101-103 + model/model.py:520-525,571-573   (embed, mask blend, CLS)
+  RegionEmbedTokens   model/modules.py:101-103 + model/model.py:520-522   (embed, mask-token blend)
+  ConcatCLS           model/model.py:523-525, 571-573   (CLS row, filled in place)
   EncoderBlock        model/transformer.py:240-248 (LN, qkv, attention, proj, residual, LN, MLP, residual)
   FinalNorm           model/transformer.py:364
   ExpressionHeadSoftplus   model/model.py:575-576
@@ -99,8 +100,13 @@ def grad_buffer(w):
     `getmi_grad_buffer`) when the parameter has no gradient yet, so autograd adopts it as `w.grad` with no copy;
     None (-> a new tensor that autograd adds into w.grad) otherwise, e.g. on later micro-batches."""
     buf = getattr(w, "getmi_grad_buffer", None)
-    if buf is None or w.grad is not None:
+    if buf is None or w.grad is not None or getattr(w, "_getmi_slot_taken", False):
         return None
+    # ONE backward node per backward pass may own the slot: a parameter used by two nodes of one graph (two forwards
+    # before one backward, siamese towers) would otherwise have both write the same memory and autograd would sum two
+    # aliases of it (2 x the last gradient).  The flag is cleared by the post-accumulate-grad hook of ddp.GradBuckets
+    # (i.e. once autograd has accumulated every contribution of this pass) and at the start of each step.
+    w._getmi_slot_taken = True
     return buf.view(buf.shape)
 
 
@@ -185,11 +191,35 @@ def w_bf16_kpad(w, kp):
 
 
 # --------------------------------------------------------------------------------------------
+def _token_layout(x):
+    """(B, N, D) if x[B,N,D] fp32 is laid out as rows 1..N of a contiguous [B,N+1,D] token buffer, else None."""
+    if x.dim() != 3 or x.dtype != torch.float32:
+        return None
+    B, N, D = x.shape
+    if x.stride() != ((N + 1) * D, D, 1) or x.storage_offset() < D:
+        return None
+    if x.untyped_storage().nbytes() < (x.storage_offset() - D + B * (N + 1) * D) * 4:
+        return None
+    return B, N, D
+
+
+def _token_alias(x):
+    """The [B,N+1,D] tensor whose rows 1..N are x (see _token_layout; no copy, not tracked by autograd)."""
+    B, N, D = x.shape
+    return torch.empty(0, dtype=x.dtype, device=x.device).set_(
+        x.untyped_storage(), x.storage_offset() - D, (B, N + 1, D), ((N + 1) * D, D, 1))
+
+
 class RegionEmbedTokens(torch.autograd.Function):
-    """tokens[B,N+1,D] fp32 = cat(cls, where(mask, mask_token, region_motif @ W^T + b))."""
+    """x[B,N,D] fp32 = where(mask, mask_token, region_motif @ W^T + b)   (model/modules.py:101-103; with mask_token
+    also the blend of model/model.py:520-525).
+
+    The result is written as rows 1..N of a [B,N+1,D] buffer and returned as that strided [B,N,D] view, so that the
+    CLS concat of model/model.py:571-573 (ConcatCLS below) fills row 0 in place instead of copying every token;
+    `region_embed`'s output keeps the reference's shape for forward hooks (run.py:359-384)."""
 
     @staticmethod
-    def forward(ctx, region_motif, weight, bias, cls_token, mask_token, mask):
+    def forward(ctx, region_motif, weight, bias, mask_token, mask):
         _need_gpu(region_motif)
         B, N, Fin = region_motif.shape
         D = weight.shape[0]
@@ -201,23 +231,29 @@ class RegionEmbedTokens(torch.autograd.Function):
         K.gemm_tn(K.EPI_EMBED, a, wb, x0, bias=bias.detach().contiguous(), mask=mask_u8,
                   mask_token=None if mask_token is None else mask_token.detach().reshape(D).contiguous(),
                   regions_per_sample=N)
-        K.fill_cls(x0, cls_token.detach().reshape(D).contiguous(), B, N + 1, D)
         ctx.save_for_backward(a, mask_u8)
         ctx.dims = (B, N, Fin, D, Kp)
         ctx.has_mask_token = mask_token is not None
         ctx.weight = weight
-        return x0
+        out = x0[:, 1:]
+        out._getmi_token_rows = True        # row 0 of every sample is ours to fill (ConcatCLS)
+        return out
 
     @staticmethod
-    def backward(ctx, dx0):
+    def backward(ctx, dx):
         a, mask_u8 = ctx.saved_tensors
         B, N, Fin, D, Kp = ctx.dims
-        dz, dcls, dmt, dbias = K.embed_bwd_prep(dx0.contiguous(), mask_u8, B, N, D)
+        if _token_layout(dx) is not None:      # the gradient ConcatCLS hands back: rows 1..N of block 0's dx, no copy
+            dx0 = _token_alias(dx)
+        else:
+            dx0 = torch.zeros(B, N + 1, D, dtype=torch.float32, device=dx.device)
+            dx0[:, 1:] = dx
+        dz, _dcls, dmt, dbias = K.embed_bwd_prep(dx0, mask_u8, B, N, D)
         dW = dIn = None
         if ctx.needs_input_grad[1]:
             dW = K.gemm_wgrad(dz, a)[:, :Fin]          # [D, Kp] -> [D, Fin]
         if ctx.needs_input_grad[0]:
-            # d(region_motif) = dz @ W   (interpretation / Jacobian use; not on the training path)
+            # d(region_motif) = dz @ W   (interpretation / Jacobian use, run.py:374-380; not on the training path)
             wt = K.cast_pad(ctx.weight.detach().t().contiguous(), _pad_to(D, 64))     # [Fin, D]
             fin_p = _pad_to(Fin, 4)
             if fin_p != Fin:
@@ -226,8 +262,33 @@ class RegionEmbedTokens(torch.autograd.Function):
             K.gemm_tn(K.EPI_F32, dz, wt, out)
             dIn = out[:, :Fin].reshape(B, N, Fin)
         return (dIn, dW, dbias if ctx.needs_input_grad[2] else None,
-                dcls.view(1, 1, D) if ctx.needs_input_grad[3] else None,
-                dmt.view(1, 1, D) if (ctx.has_mask_token and ctx.needs_input_grad[4]) else None, None)
+                dmt.view(1, 1, D) if (ctx.has_mask_token and ctx.needs_input_grad[3]) else None, None)
+
+
+class ConcatCLS(torch.autograd.Function):
+    """tokens[B,N+1,D] = cat(cls_token.expand(B,1,D), x)   (model/model.py:523-525, 571-573).  For the output of
+    RegionEmbedTokens the CLS row is filled in place; any other x is copied."""
+
+    @staticmethod
+    def forward(ctx, x, cls_token, in_place):
+        _need_gpu(x)
+        B, N, D = x.shape
+        if in_place and _token_layout(x) is not None:
+            full = _token_alias(x)
+        else:
+            full = torch.empty(B, N + 1, D, dtype=torch.float32, device=x.device)
+            full[:, 1:] = x.detach()
+        K.fill_cls(full, cls_token.detach().reshape(D).float().contiguous(), B, N + 1, D)
+        return full
+
+    @staticmethod
+    def backward(ctx, dfull):
+        dcls = dfull[:, 0].sum(0).view(1, 1, -1) if ctx.needs_input_grad[1] else None
+        return dfull[:, 1:], dcls, None
+
+
+def concat_cls(x, cls_token):
+    return ConcatCLS.apply(x, cls_token, bool(getattr(x, "_getmi_token_rows", False)))
 
 
 # --------------------------------------------------------------------------------------------
@@ -386,38 +447,87 @@ class ExpressionHeadSoftplus(torch.autograd.Function):
         return dh.view(B, T, D), dW, db
 
 
+class MaskedRows:
+    """Row lists of the masked regions of one batch (GETRegionPretrain: `x[:, 1:][mask]` and `x_original[mask]`,
+    model/model.py:527,535), built on the device at the START of forward.
+
+    The number of masked rows sets the shape of the model's output, so the host has to learn it; what it must not do
+    is wait for the encoder to find out (torch.nonzero after the encoder drains the launch queue and the GPU idles
+    while the host catches up).  The compaction kernel and an asynchronous 4-byte copy into pinned memory are
+    enqueued before the embed GEMM; `n` waits on the copy's event only when the head needs the shape, at which
+    point the copy finished long ago and the encoder's launches are already queued behind it."""
+
+    def __init__(self, mask):
+        _need_gpu(mask)
+        m = mask.reshape(mask.shape[0], -1)
+        self.B, self.N = m.shape
+        self.mask = mask
+        self.mask_u8 = m.reshape(-1).to(torch.uint8).contiguous()
+        self.token_rows, self.region_rows, count = K.mask_compact(self.mask_u8, self.B, self.N)
+        self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self._host.copy_(count, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._count = count          # keeps the device word alive until the copy has run
+        self._n = None
+
+    @property
+    def n(self):
+        if self._n is None:
+            self._event.synchronize()
+            self._n = int(self._host[0])
+        return self._n
+
+
+def w_rows_padded(w, rows_p):
+    """[R,K] fp32 -> bf16 [Rp,K], zero rows appended (cached like the other operand copies)."""
+    def make(t):
+        pad = t.new_zeros(rows_p - t.shape[0], t.shape[1])
+        return K.cast_bf16(torch.cat([t, pad], 0).contiguous())
+    return WEIGHTS.get(w, ("rpad", rows_p), make)
+
+
+def w_t_cols_padded(w, cols_p):
+    """[R,K] fp32 -> bf16 [K,Rp] = W^T with zero columns appended."""
+    def make(t):
+        wt = t.new_zeros(t.shape[1], cols_p)
+        wt[:, :t.shape[0]] = t.t()
+        return K.cast_bf16(wt)
+    return WEIGHTS.get(w, ("tpad", cols_p), make)
+
+
 class MaskedHead(torch.autograd.Function):
-    """x_masked[n_masked, out] = hf[:, 1:][mask] @ W^T + b   (row order = torch boolean indexing order)."""
+    """x_masked[n_masked, out] = hf[:, 1:][mask] @ W^T + b   (row order = torch boolean indexing order).
+    rows: MaskedRows of the same mask."""
 
     @staticmethod
-    def forward(ctx, hf, W, b, mask):
+    def forward(ctx, hf, W, b, rows):
         _need_gpu(hf)
         B, T, D = hf.shape
-        N = T - 1
         out_dim = W.shape[0]
-        m = mask.reshape(B, N)
-        flat = torch.nonzero(m.reshape(-1), as_tuple=False).squeeze(1)     # host sync: output shape is data dependent
-        idx = (flat // N) * T + 1 + (flat % N)
-        n = idx.numel()
+        if (rows.B, rows.N) != (B, T - 1):
+            raise RuntimeError("MaskedHead: mask shape does not match the token tensor")
+        n = rows.n
+        idx = rows.token_rows[:n]
         hf2 = hf.detach().reshape(B * T, D).contiguous()
         Np = _pad_to(out_dim, 4)
         ctx.dims = (B, T, D, out_dim, n)
+        ctx.W = W
         if n == 0:
-            ctx.save_for_backward(idx, hf2, W)
+            ctx.save_for_backward(idx, hf2)
             return torch.zeros(0, out_dim, dtype=torch.float32, device=hf.device)
         hsel = K.gather_rows(hf2, idx)
-        wp = torch.zeros(Np, D, dtype=torch.float32, device=hf.device)
-        wp[:out_dim] = W.detach()
-        bp = torch.zeros(Np, dtype=torch.float32, device=hf.device)
-        bp[:out_dim] = b.detach()
+        bd = b.detach()
+        bp = bd if Np == out_dim else torch.cat([bd, bd.new_zeros(Np - out_dim)])
         out = torch.empty(n, Np, dtype=torch.float32, device=hf.device)
-        K.gemm_tn(K.EPI_F32, hsel, K.cast_bf16(wp), out, bias=bp)
-        ctx.save_for_backward(idx, hsel, W)
+        K.gemm_tn(K.EPI_F32, hsel, w_rows_padded(W, Np), out, bias=bp.contiguous())
+        ctx.save_for_backward(idx, hsel)
         return out[:, :out_dim]
 
     @staticmethod
     def backward(ctx, dout):
-        idx, hsel, W = ctx.saved_tensors
+        idx, hsel = ctx.saved_tensors
+        W = ctx.W
         B, T, D, out_dim, n = ctx.dims
         dev = dout.device
         if n == 0:
@@ -425,12 +535,10 @@ class MaskedHead(torch.autograd.Function):
                     torch.zeros(out_dim, dtype=torch.float32, device=dev), None)
         Kp = _pad_to(out_dim, 64)
         dop = K.cast_pad(dout.contiguous().float(), Kp)                       # [n, Kp] bf16
-        wtp = torch.zeros(D, Kp, dtype=torch.float32, device=dev)
-        wtp[:, :out_dim] = W.detach().t()
         dhsel = torch.empty(n, D, dtype=BF16, device=dev)
-        K.gemm_tn(K.EPI_BF16, dop, K.cast_bf16(wtp), dhsel)                    # dout @ W
-        dW = K.gemm_wgrad(dop, hsel)[:out_dim]
-        db = K.colsum_bf16(dop)[:out_dim]
+        K.gemm_tn(K.EPI_BF16, dop, w_t_cols_padded(W, Kp), dhsel)              # dout @ W
+        dW = K.gemm_wgrad(dop, hsel)[:out_dim] if ctx.needs_input_grad[1] else None
+        db = K.colsum_bf16(dop)[:out_dim] if ctx.needs_input_grad[2] else None
         dh = K.gather_rows(dhsel, idx, n_out=B * T, scatter=True)
         return dh.view(B, T, D), dW, db, None
 

@@ -272,6 +272,18 @@ def gather_rows(src, idx, n_out=None, scatter=False):
     return dst
 
 
+def mask_compact(mask_u8, B, N):
+    """mask uint8 [B*N] -> (token_rows int64 [B*N], region_rows int64 [B*N], count int32 [1]); only the first
+    count[0] entries of the row lists are defined.  No host synchronisation."""
+    _chk(mask_u8)
+    dev = mask_u8.device
+    tok = torch.empty(B * N, dtype=torch.int64, device=dev)
+    reg = torch.empty(B * N, dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    lib.call("getmi_mask_compact", mask_u8, B, N, tok, reg, cnt)
+    return tok, reg, cnt
+
+
 def colsum_bf16(X, M=None):
     """Column sums of a bf16 matrix (row stride may exceed the column count: column slices are fine)."""
     if not (X.is_cuda and X.stride(1) == 1):

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "getmi_scale_cast_workspace_bytes": (_sz, [_i, _i]),
     "getmi_scale_cast": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "getmi_gather_rows_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "getmi_mask_compact": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "getmi_colsum_workspace_bytes": (_sz, [_i]),
     "getmi_colsum_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "getmi_adamw_step": (_i, [_vp, _i, _i, _vp, _i, _vp]),

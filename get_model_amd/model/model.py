@@ -66,7 +66,22 @@ class RegressionMetrics(nn.Module):
 
     @staticmethod
     def _rank(x):
-        return torch.argsort(torch.argsort(x)).to(torch.float32)
+        """Ranks 1..n with TIES AVERAGED (torchmetrics SpearmanCorrCoef, model/model.py:173-174, ranks tied values
+        by the mean of their positions; expression labels are mostly tied zeros)."""
+        n = x.numel()
+        order = torch.argsort(x, stable=True)
+        xs = x[order]
+        pos = torch.arange(1, n + 1, device=x.device, dtype=torch.float64)
+        new_run = torch.ones(n, dtype=torch.bool, device=x.device)
+        if n > 1:
+            new_run[1:] = xs[1:] != xs[:-1]
+        run = torch.cumsum(new_run.to(torch.int64), 0) - 1                  # run index of every sorted element
+        nrun = int(run[-1].item()) + 1 if n else 0
+        tot = torch.zeros(nrun, dtype=torch.float64, device=x.device).index_add_(0, run, pos)
+        cnt = torch.zeros(nrun, dtype=torch.float64, device=x.device).index_add_(0, run, torch.ones_like(pos))
+        ranks = torch.empty(n, dtype=torch.float64, device=x.device)
+        ranks[order] = (tot / cnt)[run]
+        return ranks.to(torch.float32)
 
     @staticmethod
     def _pearson(a, b):
@@ -165,16 +180,25 @@ class GETRegionPretrain(BaseGETModel):
         return {"region_motif": batch["region_motif"], "mask": batch["mask"].unsqueeze(-1).bool()}
 
     def forward(self, region_motif, mask):
-        x = self.region_embed(region_motif, cls_token=self.cls_token, mask_token=self.mask_token, mask=mask)
+        rows = Fn.MaskedRows(mask)              # device-side row lists of x[:, 1:][mask]; see functional.MaskedRows
+        x = self.region_embed(region_motif, mask_token=self.mask_token, mask=mask)      # embed + blend (:520-522)
+        x = Fn.concat_cls(x, self.cls_token)                                             # :523-525
         x, _ = self.encoder(x)
-        x_masked = Fn.MaskedHead.apply(x, self.head_mask.weight, self.head_mask.bias, mask)
+        x_masked = Fn.MaskedHead.apply(x, self.head_mask.weight, self.head_mask.bias, rows)   # :527-528
+        x_masked._getmi_rows = rows
         return x_masked, region_motif, mask
 
     def before_loss(self, output, batch):
         x_masked, x_original, loss_mask = output
         B, _, C = x_original.shape
         pred = {"masked": x_masked}
-        obs = {"masked": x_original[loss_mask.squeeze(-1)].reshape(-1, C)}
+        rows = getattr(x_masked, "_getmi_rows", None)
+        if rows is not None and rows.mask is loss_mask and x_original.is_cuda:
+            # same rows, same order as x_original[loss_mask.squeeze(-1)] (:535), from the row list forward already built
+            target = x_original.reshape(-1, C).index_select(0, rows.region_rows[:rows.n])
+        else:
+            target = x_original[loss_mask.squeeze(-1)].reshape(-1, C)
+        obs = {"masked": target}
         return pred, obs
 
     def generate_dummy_data(self):
@@ -197,7 +221,8 @@ class GETRegionFinetune(BaseGETModel):
         return {"region_motif": batch["region_motif"]}
 
     def forward(self, region_motif):
-        x = self.region_embed(region_motif, cls_token=self.cls_token)
+        x = self.region_embed(region_motif)
+        x = Fn.concat_cls(x, self.cls_token)            # model/model.py:571-573
         x, _ = self.encoder(x)
         return self.head_exp(x)          # drops CLS, Linear, Softplus (fused)
 
@@ -226,7 +251,8 @@ class GETRegionFinetuneATAC(BaseGETModel):
         return {"region_motif": inp}
 
     def forward(self, region_motif):
-        x = self.region_embed(region_motif, cls_token=self.cls_token)
+        x = self.region_embed(region_motif)
+        x = Fn.concat_cls(x, self.cls_token)            # model/model.py:571-573
         x, _ = self.encoder(x)
         return self.head_exp(x)
 

@@ -51,22 +51,19 @@ class BaseModule(nn.Module):
 class RegionEmbed(BaseModule):
     """reference: model/modules.py:93-106 (`nn.Linear(num_features, embed_dim)` named `embed`).
 
-    `forward(x)` returns the [B,N,D] embedding like the reference.  The region models call it with
-    `cls_token=` (and, for pre-training, `mask_token=`/`mask=`) so that the mask-token blend and the CLS
-    concat of model/model.py:520-525,571-573 are fused into the GEMM epilogue; it then returns the full
-    [B,N+1,D] token tensor.
+    `forward(x)` returns the [B,N,D] fp32 embedding like the reference (what a forward hook on `region_embed`
+    captures, run.py:359-384).  The tensor is a strided view: rows 1..N of a [B,N+1,D] buffer whose row 0 the CLS
+    concat of the region models (functional.concat_cls) fills in place.  GETRegionPretrain also passes
+    `mask_token=` / `mask=`: the blend of model/model.py:520-522 is then fused into the GEMM epilogue, so for that
+    model the hooked output already holds the mask tokens (the one visible difference from the reference).
     """
 
     def __init__(self, cfg):
         super().__init__(cfg)
         self.embed = nn.Linear(cfg.num_features, cfg.embed_dim)
 
-    def forward(self, x, cls_token=None, mask_token=None, mask=None, **kwargs):
-        w, b = self.embed.weight, self.embed.bias
-        if cls_token is None:
-            zeros = torch.zeros(1, 1, w.shape[0], dtype=torch.float32, device=x.device)
-            return Fn.RegionEmbedTokens.apply(x, w, b, zeros, None, None)[:, 1:]
-        return Fn.RegionEmbedTokens.apply(x, w, b, cls_token, mask_token, mask)
+    def forward(self, x, mask_token=None, mask=None, **kwargs):
+        return Fn.RegionEmbedTokens.apply(x, self.embed.weight, self.embed.bias, mask_token, mask)
 
     def generate_dummy_data(self, batch_size=1):
         return torch.rand(batch_size, 5, self.cfg.num_features)

@@ -165,6 +165,10 @@ class FusedAdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._sig = None            # the cached job table points at the moment tensors that were just replaced
+
     def _build(self, entries):
         """entries: (p, grad, m, v, wn, wt, group index) -> device job table."""
         flat, tile = [], []
@@ -196,15 +200,12 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if len(self.param_groups) > 64:
-            raise RuntimeError("FusedAdamW: more than 64 parameter groups")
         cache = Fn.WEIGHTS
         cache.epoch += 1            # every cached copy is stale from here on, except the ones re-tagged below
-        entries, groups, sig = [], (_Group * len(self.param_groups))(), []
-        retag = []
+        entries, sig = [], []
+        table = {}      # (param group, step count) -> row of the hyper-parameter table: bias correction is per parameter
+        retag = []      # in torch.optim.AdamW, so parameters of one group whose step counts differ get rows of their own
         for gi, grp in enumerate(self.param_groups):
-            b1, b2 = grp["betas"]
-            t = None
             for p in grp["params"]:
                 if p.grad is None:
                     continue
@@ -214,20 +215,27 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW needs dense contiguous fp32 parameters and gradients")
                 st = self._state(p)
                 st["step"] += 1
-                t = float(st["step"])
+                ti = table.setdefault((gi, float(st["step"])), len(table))
                 wn = cache.peek(p, "n")
                 wt = cache.peek(p, "t")
                 if wt is not None and not (p.ndim == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0):
                     wt = None
-                entries.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], wn, wt, gi))
-                sig.append((p.data_ptr(), p.grad.data_ptr(), 0 if wn is None else wn.data_ptr(),
-                            0 if wt is None else wt.data_ptr(), gi))
+                entries.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], wn, wt, ti))
+                # every pointer the job table holds is part of the signature: load_state_dict() replaces the moment
+                # tensors while parameter and gradient addresses stay put
+                sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                            0 if wn is None else wn.data_ptr(), 0 if wt is None else wt.data_ptr(), ti))
                 if wn is not None:
                     retag.append((p, "n"))
                 if wt is not None:
                     retag.append((p, "t"))
-            t = 1.0 if t is None else t
-            g = groups[gi]
+        if len(table) > 64:
+            raise RuntimeError("FusedAdamW: more than 64 (parameter group, step count) combinations")
+        groups = (_Group * max(len(table), 1))()
+        for (gi, t), ti in table.items():
+            grp = self.param_groups[gi]
+            b1, b2 = grp["betas"]
+            g = groups[ti]
             g.lr, g.weight_decay, g.beta1, g.beta2, g.eps = grp["lr"], grp["weight_decay"], b1, b2, grp["eps"]
             g.step_size = grp["lr"] / (1.0 - b1 ** t)
             g.inv_sqrt_bc2 = 1.0 / math.sqrt(1.0 - b2 ** t)
@@ -237,7 +245,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if sig != self._sig:       # pointers are stable with ddp.GradBuckets; rebuilt only when something moved
             self._build(entries)
             self._sig = sig
-        lib.call("getmi_adamw_step", self._jobs, self._nflat, self._ntile, ctypes.addressof(groups), len(self.param_groups))
+        lib.call("getmi_adamw_step", self._jobs, self._nflat, self._ntile, ctypes.addressof(groups), len(table))
         for p, kind in retag:
             cache.retag(p, kind)
         return loss

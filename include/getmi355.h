@@ -116,6 +116,12 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
 /* ---- masked-row gather/scatter (model/model.py:527,535), column sums (bias gradients) ----------- */
 int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int D, int scatter,
                            void* stream);
+/* Row lists of the masked regions of mask[B,N] (uint8, non-zero = masked) in ascending order, i.e. the row order of
+ * the boolean indexing `x[:, 1:][mask]` / `x_original[mask]` (model/model.py:527,535): token_rows[i] = b*(N+1)+1+r
+ * (rows of the [B*(N+1), D] token matrix), region_rows[i] = b*N+r; count[0] = number of masked regions.  All device
+ * memory, sized B*N; nothing is read back by the library (the caller reads `count` when it needs the shape). */
+int getmi_mask_compact(const uint8_t* mask, int B, int N, int64_t* token_rows, int64_t* region_rows, int* count,
+                       void* stream);
 size_t getmi_colsum_workspace_bytes(int N);
 int getmi_colsum_bf16(const void* X, float* out, int accumulate, int M, int N, int ld, void* workspace,
                       size_t workspace_bytes, void* stream);

@@ -117,3 +117,60 @@ def test_fused_adamw_matches_torch_adamw_and_refreshes_bf16_copies():
     # optimizer state uses torch's names
     st = next(iter(oa.state.values()))
     assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 3.0
+
+
+@pytest.mark.gpu
+def test_fused_adamw_load_state_dict_and_uneven_step_counts():
+    """(a) after load_state_dict() the cached job table must point at the NEW moment tensors (parameter
+    and gradient addresses do not change, so they alone cannot key the cache); (b) bias correction follows each
+    parameter's own step count (torch.optim.AdamW), e.g. for a parameter that had no gradient in earlier steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.manual_seed(3)
+    shapes = [(64, 128), (128,), (192, 64), (7,)]
+    pa = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = O.FusedAdamW([{"params": pa[:2], "weight_decay": 0.05}, {"params": pa[2:], "weight_decay": 0.0}], lr=1e-2)
+    ob = torch.optim.AdamW([{"params": pb[:2], "weight_decay": 0.05}, {"params": pb[2:], "weight_decay": 0.0}], lr=1e-2)
+    grads = [[torch.randn_like(p) for p in pa] for _ in range(5)]
+
+    def step(i, skip=()):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k in skip:
+                a.grad = b.grad = None
+            else:
+                # gradients at fixed addresses, as with ddp.GradBuckets: only the moment tensors change below
+                if a.grad is None:
+                    a.grad = grads[i][k].clone()
+                else:
+                    a.grad.copy_(grads[i][k])
+                b.grad = grads[i][k].clone()
+        oa.step()
+        ob.step()
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            torch.testing.assert_close(a, b, rtol=3e-6, atol=3e-7, msg=lambda s, k=k: f"param {k} step {i}: {s}")
+
+    step(0, skip=(1, 3))        # parameters 1 and 3 start one step late: their bias correction lags by one
+    step(1)
+    snap_a, snap_b = oa.state_dict(), ob.state_dict()
+    import copy
+    snap_a, snap_b = copy.deepcopy(snap_a), copy.deepcopy(snap_b)
+    weights = [p.detach().clone() for p in pa]
+    step(2)
+    step(3)
+    # roll back: new moment tensors, same parameter / gradient addresses
+    oa.load_state_dict(snap_a)
+    ob.load_state_dict(snap_b)
+    with torch.no_grad():
+        for a, b, w in zip(pa, pb, weights):
+            a.copy_(w)
+            b.copy_(w)
+    step(2)
+    step(4)
+    for a in pa:        # the restored moments are the ones being updated
+        st = oa.state[a]
+        assert st["exp_avg"].abs().sum().item() > 0
+    # state dicts are interchangeable with torch.optim.AdamW's
+    for sa, sb in zip(oa.state_dict()["state"].values(), ob.state_dict()["state"].values()):
+        torch.testing.assert_close(sa["exp_avg"], sb["exp_avg"], rtol=3e-6, atol=1e-7)
+        assert float(sa["step"]) == float(sb["step"])
