@@ -63,6 +63,7 @@ __device__ __forceinline__ uint4 stage_row_chunk(const char* blk, int row, int c
 struct AttnFwdArgs {
     const bf16_t* qkv;
     bf16_t* out;
+    bf16_t* out_lo;   // optional [B,T,H*64]: bf16(O - float(out)), the rounding residual of `out` (see attn_bwd_kernel: delta)
     float* lse;
     int B, T, H;
     float scale;
@@ -216,6 +217,27 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
             if (q0 + row < T)
                 *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8) = v;
         }
+        if (p.out_lo != nullptr) {
+            // what the bf16 rounding of O dropped: the backward forms delta = rowsum(dO * O) from out + out_lo
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = db * 32 + 8 * g4 + 4 * h2;
+                    const float v0 = o[db][4 * g4] * inv, v1 = o[db][4 * g4 + 1] * inv, v2 = o[db][4 * g4 + 2] * inv,
+                                v3 = o[db][4 * g4 + 3] * inv;
+                    const uint2 hi = pack4bf(v0, v1, v2, v3);
+                    stage_row_piece(blk, r, d0, pack4bf(v0 - bf2f(hi.x & 0xffff), v1 - bf2f(hi.x >> 16),
+                                                        v2 - bf2f(hi.y & 0xffff), v3 - bf2f(hi.y >> 16)));
+                }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = stage_row_chunk(blk, row, ch);
+                if (q0 + row < T)
+                    *reinterpret_cast<uint4*>(p.out_lo + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8) = v;
+            }
+        }
     }
 }
 
@@ -240,6 +262,10 @@ extern "C" int getmi_debug_attn_stamps(void* dst, size_t bytes) {
 struct AttnBwdArgs {
     const bf16_t* qkv;
     const bf16_t* out;    // [B,T,H*64] forward output (for delta = rowsum(dO * O))
+    const bf16_t* out_lo; // optional: the forward's rounding residual of `out`.  delta from the bf16 output alone breaks
+                          // sum_key dS[q][key] = 0 by dO.(O - bf16(O)) per row, which is harmless everywhere except in the
+                          // q_bias gradient (a pure cancellation sum): 8-23 % error there in a 12-layer model vs 0.6 %
+                          // with the residual (profiles/r02_qbias_error.txt)
     const bf16_t* dout;   // [B,T,H*64]
     const float* lse;     // [B,H,T]
     bf16_t* dqkv;         // [B,T,3,H,64]
@@ -309,7 +335,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
     bf16x8 kfr[4];   // this wave's K rows as the B operand of S = Q.K^T           (slice-invariant, kept in VGPRs)
     bf16x8 ktf[8];   // K^T fragments of all 256 keys for this wave's dQ d-block   (slice-invariant, kept in VGPRs)
-    f32x4 dqs = {0.f, 0.f, 0.f, 0.f};   // running sum over queries of this wave's dQ tiles (q_bias gradient)
+    float dssum = 0.f;   // running sum over queries of this lane's fp32 dS / scale column (q_bias gradient, see the end)
     float* stf = reinterpret_cast<float*>(smem + BW_ST);
     int dsbuf = 0;
     STAMP(1);
@@ -337,13 +363,27 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             if (qi < T) {
                 const uint4* po = reinterpret_cast<const uint4*>(obase + (size_t)qi * (H * HD) + (tid & 1) * 32);
                 const uint4* pd = reinterpret_cast<const uint4*>(dobase + (size_t)qi * (H * HD) + (tid & 1) * 32);
+                if (p.out_lo != nullptr) {       // workgroup-uniform
+                    const uint4* pl = reinterpret_cast<const uint4*>(p.out_lo + ((size_t)b * T + qi) * (H * HD) + h * HD +
+                                                                      (tid & 1) * 32);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint4 a = po[k], d = pd[k];
-                    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+                    for (int k = 0; k < 4; ++k) {
+                        const uint4 a = po[k], d = pd[k], e = pl[k];
+                        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w}, ew[4] = {e.x, e.y, e.z, e.w};
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        acc += bf2f(aw[w] & 0xffff) * bf2f(dw[w] & 0xffff) + bf2f(aw[w] >> 16) * bf2f(dw[w] >> 16);
+                        for (int w = 0; w < 4; ++w)
+                            acc += (bf2f(aw[w] & 0xffff) + bf2f(ew[w] & 0xffff)) * bf2f(dw[w] & 0xffff) +
+                                   (bf2f(aw[w] >> 16) + bf2f(ew[w] >> 16)) * bf2f(dw[w] >> 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint4 a = po[k], d = pd[k];
+                        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            acc += bf2f(aw[w] & 0xffff) * bf2f(dw[w] & 0xffff) + bf2f(aw[w] >> 16) * bf2f(dw[w] >> 16);
+                    }
                 }
             }
             acc += __shfl_xor(acc, 1, 64);
@@ -407,6 +447,11 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                         dp[i] = kvalid ? dp[i] : 0.f;
                     }
                 }
+                // column sums of dS for the q_bias gradient, taken HERE from the fp32 values: d(q_bias) = sum_q dQ[q] =
+                // scale * sum_key (sum_q dS[q][key]) K[key] is a cancellation sum (every row of dS sums to ~0), and summing
+                // the dQ tiles instead, which are built from the bf16-rounded dS image, leaves it at that rounding's floor
+                dssum += (((dp[0] + dp[1]) + (dp[2] + dp[3])) + ((dp[4] + dp[5]) + (dp[6] + dp[7]))) +
+                         (((dp[8] + dp[9]) + (dp[10] + dp[11])) + ((dp[12] + dp[13]) + (dp[14] + dp[15])));
                 bf16x8 pf[2], dsf[2];
                 pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
                 pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
@@ -461,7 +506,6 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                         acc = MFMA16(ktf[ks], dst, acc);   // D[d][q] = sum_key K[key][d] dS[q][key]
                     }
                 }
-                dqs += acc;        // rows of padded queries are exactly 0 (P = 0 there)
                 const int q = qc + sl * 32 + qh * 16 + (lane & 15);
                 const int d0 = dblk * 16 + (lane >> 4) * 4;
                 if (q < T) {
@@ -489,7 +533,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
         //      dV: lane = key, registers = d -> reduce over the 32 lanes of each half wave; columns of padded keys
         //      are exactly 0.  dQ: lane&15 = query -> reduce over 16 lanes.  Then across waves through LDS.
         __syncthreads();                                   // every wave is done with the dS images: reuse them
-        float* red = reinterpret_cast<float*>(smem + BW_DS);          // [8 waves][64] dV | [2 q-halves][64] dQ at +512
+        float* red = reinterpret_cast<float*>(smem + BW_DS);          // [8 waves][64] dV | [8 waves][64] dQ at +512
         {
             // butterfly reduce-scatter over the 32 lanes of a half wave: 16+8+4+2+1 exchanges instead of 32 x 5;
             // lane r ends with the sum over keys of accumulator register r (= db*16 + i)
@@ -509,23 +553,33 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             red[wave * 64 + (r >> 4) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = v[0];
         }
         {
-            // dQ: 4 registers over the 16 lanes that share (lane >> 4): reduce-scatter over lane bits 3, 2, then sum
-            // over bits 1, 0; lanes with (lane & 3) == 0 hold register j = (lane >> 2) & 3
-            const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
-            float a0 = (u8 ? dqs[2] : dqs[0]) + __shfl_xor(u8 ? dqs[0] : dqs[2], 8, 64);
-            float a1 = (u8 ? dqs[3] : dqs[1]) + __shfl_xor(u8 ? dqs[1] : dqs[3], 8, 64);
-            float v = (u4 ? a1 : a0) + __shfl_xor(u4 ? a0 : a1, 4, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 1, 64);
-            const int j = ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-            if ((lane & 3) == 0) red[512 + (wave & 1) * 64 + (wave >> 1) * 16 + (lane >> 4) * 4 + j] = v;
+            // dQ: partial[d] = sum over this wave's 32 keys of (sum_q dS[q][key]) * K[key][d], d = lane.  The K image is
+            // still whole (the dK / dV staging below overwrites it only after the next barrier); rows of waves past T
+            // were never staged, hence the wave_active guard (their column sums are 0 anyway).
+            const float cs = dssum + __shfl_xor(dssum, 32, 64);      // both query halves of key r
+            float part = 0.f;
+            if (wave_active) {
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) {
+                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), rr));
+                    const int krow = wave * 32 + rr;
+                    const bf16_t kv = *reinterpret_cast<const bf16_t*>(
+                        smem + BW_KIMG + krow * 128 + ((((lane >> 3) ^ swz128(krow)) << 4) | ((lane & 7) << 1)));
+                    part = fmaf(c, bf2f(kv), part);
+                }
+            }
+            red[512 + wave * 64 + lane] = part;
         }
         __syncthreads();
         if (tid < 128) {
             const int d = tid & 63;
             float v;
-            if (tid < 64) v = (red[512 + d] + red[576 + d]) * p.scale;
-            else {
+            if (tid < 64) {
+                v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[512 + w * 64 + d];
+                v *= p.scale;
+            } else {
                 v = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
@@ -579,11 +633,12 @@ __global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
-int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, int B, int T, int H, float scale,
+int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, bf16_t* out_lo, float* lse, int B, int T, int H, float scale,
                         hipStream_t st) {
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_fwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "attn_fwd: pointers must be 16-byte aligned");
-    AttnFwdArgs a{qkv, out, lse, B, T, H, scale};
+    GETMI_CHECK_ARG((uintptr_t)out_lo % 16 == 0, "attn_fwd: out_lo must be 16-byte aligned");
+    AttnFwdArgs a{qkv, out, out_lo, lse, B, T, H, scale};
     // waves (= 32-query groups) per workgroup: 8 (256 queries: K/V of a (b, h) staged once for T <= 256, one staging
     // instruction per wave and chunk) unless 4 already cover T.  Measured at T = 201: 104 us vs 111 (4 waves) and 118
     // (7 waves: the staging no longer divides evenly); T = 2001: 366 vs 375.  GETMI_ATTN_FWD_WAVES overrides (4..8)
@@ -613,13 +668,13 @@ size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
                          hipStream_t st);
 
-int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv,
+int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_lo, const bf16_t* dout, const float* lse, bf16_t* dqkv,
                         float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
                         size_t workspace_bytes, hipStream_t st) {
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_attn_bwd_workspace_bytes(B, T, H), "attn_bwd: workspace too small");
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
-                        ((uintptr_t)out % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
+                        ((uintptr_t)out % 16 == 0) && ((uintptr_t)out_lo % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
                     "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
     float* dq_acc = nullptr;
     if (T > 256) dq_acc = reinterpret_cast<float*>(workspace);   // every slab element is written by its key block
@@ -632,7 +687,7 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout
     const bool want_bias = dq_bias != nullptr || dv_bias != nullptr;
     float* bias_partial = want_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + attn_bwd_slab_bytes(B, T, H))
                                     : nullptr;
-    AttnBwdArgs a{qkv, out, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale};
+    AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale};
     const int nkb = (T + 255) / 256;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");

@@ -23,9 +23,9 @@ int getmi_ln_fwd_impl(const float*, const float*, const float*, bf16_t*, float*,
 size_t getmi_ln_bwd_workspace_bytes(int M, int D);
 int getmi_ln_bwd_impl(const bf16_t*, const float*, const float*, const float*, const float*, const float*, const float*,
                       int, float*, bf16_t*, float*, float*, float*, int, int, int, void*, size_t, hipStream_t);
-int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, float*, int, int, int, float, hipStream_t);
+int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, bf16_t*, float*, int, int, int, float, hipStream_t);
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H);
-int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, float*, float*, int, int, int,
+int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, float*, float*, int, int, int,
                         float, void*, size_t, hipStream_t);
 int getmi_cast_pad_impl(const float*, bf16_t*, size_t, int, int, hipStream_t);
 int getmi_cast_transpose_impl(const float*, bf16_t*, int, int, hipStream_t);
@@ -111,14 +111,15 @@ int getmi_layernorm_bwd(const void* dy, const float* x, const float* mean, const
     return getmi_ln_bwd_impl(BF(dy), x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, BFW(dz), dgamma, dbeta,
                              dbias_prev, accumulate, M, D, workspace, workspace_bytes, ST(stream));
 }
-int getmi_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale, void* stream) {
-    return getmi_attn_fwd_impl(BF(qkv), BFW(out), lse, B, T, H, scale, ST(stream));
+int getmi_attention_fwd(const void* qkv, void* out, void* out_lo, float* lse, int B, int T, int H, float scale,
+                        void* stream) {
+    return getmi_attn_fwd_impl(BF(qkv), BFW(out), BFW(out_lo), lse, B, T, H, scale, ST(stream));
 }
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H) { return getmi_attn_bwd_workspace_bytes(B, T, H); }
-int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
+int getmi_attention_bwd(const void* qkv, const void* out, const void* out_lo, const void* dout, const float* lse,
+                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
                         size_t workspace_bytes, void* stream) {
-    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(dout), lse, BFW(dqkv), dq_bias, dv_bias, B, T, H, scale, workspace,
+    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(out_lo), BF(dout), lse, BFW(dqkv), dq_bias, dv_bias, B, T, H, scale, workspace,
                                workspace_bytes, ST(stream));
 }
 int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream) {

@@ -178,6 +178,7 @@ class _GradHandoff:
 
 
 _USE_HANDOFF = os.environ.get("GETMI_HANDOFF", "1") != "0"      # 0: always scale_cast (A/B measurements)
+_ATTN_LO = os.environ.get("GETMI_ATTN_LO", "1") != "0"          # 0: delta from the bf16 attention output alone (A/B)
 HANDOFF = _GradHandoff()
 
 
@@ -315,14 +316,19 @@ class EncoderBlock(torch.autograd.Function):
         h1, mean1, rstd1 = K.layernorm_fwd(x2, n1w.detach(), n1b.detach(), eps)
         qkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, h1, w_bf16(qkv_w), qkv, bias=K.qkv_bias(q_bias.detach(), v_bias.detach()))
-        a, lse = K.attention_fwd(qkv, B, T, H, att_scale)
+        # (the residual of the bf16 output is kept only when q_bias will get a gradient: see kernels.attention_fwd)
+        needs_bwd = any(ctx.needs_input_grad)      # all False under no_grad / inference_mode
+        a_lo = None
+        if needs_bwd and ctx.needs_input_grad[4] and _ATTN_LO:
+            a, lse, a_lo = K.attention_fwd(qkv, B, T, H, att_scale, want_lo=True)
+        else:
+            a, lse = K.attention_fwd(qkv, B, T, H, att_scale)
         x_mid = torch.empty(M, D, dtype=torch.float32, device=dev)
         K.gemm_tn(K.EPI_BIAS_RESID, a, w_bf16(proj_w), x_mid, bias=proj_b.detach(), resid=x2, rowscale=scale1,
                   rows_per_sample=T)
         # --- MLP branch ---
         h2, mean2, rstd2 = K.layernorm_fwd(x_mid, n2w.detach(), n2b.detach(), eps)
         Fh = fc1_w.shape[0]
-        needs_bwd = any(ctx.needs_input_grad)      # all False under no_grad / inference_mode
         u = torch.empty(M, Fh, dtype=BF16, device=dev) if needs_bwd else None     # inference: gelu'(.) is not stored
         g = torch.empty(M, Fh, dtype=BF16, device=dev)
         # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply
@@ -331,7 +337,7 @@ class EncoderBlock(torch.autograd.Function):
         K.gemm_tn(K.EPI_BIAS_RESID, g, w_bf16(fc2_w), x_out, bias=fc2_b.detach(), resid=x_mid, rowscale=scale2,
                   rows_per_sample=T)
         ctx.save_for_backward(x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2,
-                              n1w, n2w)
+                              n1w, n2w, a_lo)
         ctx.weights = (qkv_w, proj_w, fc1_w, fc2_w)
         ctx.dims = (B, T, D, H, att_scale)
         ctx.up = (bool(up_block), up_scale)
@@ -339,7 +345,7 @@ class EncoderBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx_out):
-        (x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2, n1w, n2w) = ctx.saved_tensors
+        (x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2, n1w, n2w, a_lo) = ctx.saved_tensors
         qkv_w, proj_w, fc1_w, fc2_w = ctx.weights
         B, T, D, H, att_scale = ctx.dims
         M = B * T
@@ -374,7 +380,7 @@ class EncoderBlock(torch.autograd.Function):
         # backward's fp32 accumulators
         dq_bias = dv_bias = None
         if need[4] or need[5]:
-            dqkv, dq_bias, dv_bias = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, want_bias=True)
+            dqkv, dq_bias, dv_bias = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, want_bias=True, out_lo=a_lo)
         else:
             dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale)
         if pair:

@@ -161,26 +161,28 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, rowscale=None, rows_per_s
     return dx, dz, dgamma, dbeta, dbias
 
 
-def attention_fwd(qkv, B, T, H, scale):
-    """qkv bf16 [B*T, 3*H*64] (packed [B,T,3,H,64]) -> (out bf16 [B*T, H*64], lse fp32 [B,H,T])."""
+def attention_fwd(qkv, B, T, H, scale, want_lo=False):
+    """qkv bf16 [B*T, 3*H*64] (packed [B,T,3,H,64]) -> (out bf16 [B*T, H*64], lse fp32 [B,H,T]); with want_lo also
+    the rounding residual bf16(O - out) that attention_bwd takes as out_lo."""
     _chk(qkv)
     out = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device)
+    lo = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device) if want_lo else None
     lse = torch.empty(B, H, T, dtype=F32, device=qkv.device)
     e0 = _prof_begin()
-    lib.call("getmi_attention_fwd", qkv, out, lse, B, T, H, float(scale))
+    lib.call("getmi_attention_fwd", qkv, out, lo, lse, B, T, H, float(scale))
     _prof_end(e0, "attn_fwd_kernel", 4.0 * B * H * T * T * 64)
-    return out, lse
+    return (out, lse, lo) if want_lo else (out, lse)
 
 
-def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False):
+def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False, out_lo=None):
     """-> dqkv, or (dqkv, dq_bias [H*64], dv_bias [H*64]) with want_bias (column sums of the Q / V thirds, fp32)."""
-    _chk(qkv, out, dout, lse)
+    _chk(qkv, out, dout, lse, out_lo)
     dqkv = torch.empty_like(qkv)
     dqb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     dvb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
     e0 = _prof_begin()
-    lib.call("getmi_attention_bwd", qkv, out, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), ws, ws.numel())
+    lib.call("getmi_attention_bwd", qkv, out, out_lo, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), ws, ws.numel())
     _prof_end(e0, "attn_bwd_kernel(+delta)", 10.0 * B * H * T * T * 64)
     return (dqkv, dqb, dvb) if want_bias else dqkv
 

@@ -29,9 +29,9 @@ _SIGNATURES = {
     "getmi_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "getmi_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "getmi_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "getmi_attention_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "getmi_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "getmi_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "getmi_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "getmi_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _vp]),
     "getmi_fill_cls": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "getmi_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_embed_bwd_prep": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

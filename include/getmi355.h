@@ -74,12 +74,18 @@ int getmi_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, 
                         int M, int D, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- attention (model/transformer.py:58-96), packed qkv[B,T,3,H,64] bf16, head_dim 64 ---------- */
-int getmi_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale, void* stream);
+/* out_lo (may be null): bf16(O - float(out)), what the bf16 rounding of the output dropped.  The backward forms
+ * delta = rowsum(dO * O) from out + out_lo: with the rounded output alone every row of dS misses sum 0 by
+ * dO.(O - bf16(O)), which only the q_bias gradient (a cancellation sum over all of dS) can see. */
+int getmi_attention_fwd(const void* qkv, void* out, void* out_lo, float* lse, int B, int T, int H, float scale,
+                        void* stream);
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H);
-/* dq_bias / dv_bias (each [H*64] fp32, may be null): column sums over all tokens of the Q and V thirds of dqkv, taken
- * from the fp32 accumulators -- the gradients of Attention.q_bias / v_bias (model/transformer.py:52-57). */
-int getmi_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
+/* dq_bias / dv_bias (each [H*64] fp32, may be null): the gradients of Attention.q_bias / v_bias
+ * (model/transformer.py:52-57) = column sums over all tokens of the Q and V thirds of d(qkv), taken in fp32
+ * (dq_bias = scale * sum_key (sum_q dS[q][key]) K[key] from the fp32 dS; dv_bias from the dV accumulators).
+ * out_lo: the forward's residual output, or null. */
+int getmi_attention_bwd(const void* qkv, const void* out, const void* out_lo, const void* dout, const float* lse,
+                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
                         size_t workspace_bytes, void* stream);
 
 /* ---- region embed glue (model/model.py:520-525,571-573) ---------------------------------------- */

@@ -32,13 +32,11 @@ def load_case(name):
 
 
 def _group_name(name):
-    """attn.q_bias / attn.v_bias are two slices of ONE bias vector of the packed QKV projection in the reference
-    (`torch.cat((q_bias, 0, v_bias))`, model/transformer.py:50-56); their gradients are checked as that one vector.
-    Reason: d(q_bias) = sum_rows dQ is a pure cancellation sum (each row of the softmax Jacobian sums to zero), its
-    magnitude is ~1e-2..1e-3 of d(v_bias), so on its own it sits at the bf16 rounding floor of dS (8 mantissa
-    bits) -- inherent to any bf16 attention backward, measured at 5-27 % relative for a 12-layer model."""
-    if name.endswith("attn.q_bias") or name.endswith("attn.v_bias"):
-        return name.rsplit(".", 1)[0] + ".qv_bias"
+    """Every parameter is checked on its own.  (Round 1 checked attn.q_bias only fused with attn.v_bias: its gradient
+    is a pure cancellation sum -- each row of the softmax Jacobian sums to zero -- and was off by 5-45 % alone.  The
+    cause was delta = rowsum(dO * O) taken from the bf16-ROUNDED attention output, which breaks that zero row sum by
+    dO.(O - bf16(O)); with the forward's rounding residual added back (attention `out_lo`) q_bias is within 1.5 % of its
+    scale at 12 layers: profiles/r02_qbias_error.txt.)"""
     return name
 
 
