@@ -49,6 +49,8 @@ int getmi_colsum_bf16_impl(const bf16_t*, float*, int, int, int, int, void*, siz
 
 size_t getmi_scale_cast_workspace_bytes_impl(int M, int D);
 int getmi_scale_cast_impl(const float*, const float*, int, bf16_t*, float*, int, int, int, void*, size_t, hipStream_t);
+size_t getmi_scale_cast_noalloc_max_bytes_impl(void);
+int getmi_scale_cast_noalloc_impl(const float*, const float*, int, bf16_t*, float*, int, int, int, hipStream_t);
 
 struct AdamGroup { float lr, weight_decay, beta1, beta2, eps, step_size, inv_sqrt_bc2, pad; };
 int getmi_adamw_step_impl(const void* jobs, int nflat, int ntile, const AdamGroup* groups, int ngroups, hipStream_t st);
@@ -168,6 +170,11 @@ size_t getmi_loss_workspace_bytes(void) { return getmi_loss_workspace_bytes_impl
 size_t getmi_colsum_workspace_bytes(int N) { return getmi_colsum_workspace_bytes_impl(N); }
 
 size_t getmi_scale_cast_workspace_bytes(int M, int D) { return getmi_scale_cast_workspace_bytes_impl(M, D); }
+size_t getmi_scale_cast_noalloc_max_bytes(void) { return getmi_scale_cast_noalloc_max_bytes_impl(); }
+int getmi_scale_cast_noalloc(const float* dx, const float* rowscale, int rows_per_sample, void* dz, float* dbias,
+                             int accumulate, int M, int D, void* stream) {
+    return getmi_scale_cast_noalloc_impl(dx, rowscale, rows_per_sample, BFW(dz), dbias, accumulate, M, D, ST(stream));
+}
 int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample, void* dz, float* dbias, int accumulate,
                      int M, int D, void* workspace, size_t workspace_bytes, void* stream) {
     return getmi_scale_cast_impl(dx, rowscale, rows_per_sample, BFW(dz), dbias, accumulate, M, D, workspace,

@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the GET region hot path: casts/packing, region-embed glue, expression head,
 // losses, row gather/scatter, column sums.  All are simple streaming kernels with 8-16 B per-lane accesses.
 #include "common.h"
+#include <mutex>
 
 #define GRID_CAP 2048
 
@@ -453,6 +454,53 @@ int getmi_scale_cast_impl(const float* dx, const float* rowscale, int rows_per_s
     }
     GETMI_CHECK_LAUNCH("scale_cast");
     return getmi_colreduce_impl(partial, dbias, nullptr, nullptr, g, D, accumulate, st);
+}
+
+// ---- getmi_scale_cast_noalloc: the same two kernels with the column-sum partials in a built-in device buffer -------------
+// For callers that cannot allocate or pass a workspace (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc).  `g_scale_cast_scratch` is a file-scope device array: in HOST code its name is only a handle, never a
+// device address, so the address every kernel launch and every other host-side use takes is the one
+// hipGetSymbolAddress returns, looked up once per device (each GPU holds its own copy at its own address).
+#define SCALE_CAST_SCRATCH_BYTES (3u << 20)      // 3 MiB: 1024 partial rows x 768 columns x 4 B (the largest grid at D = 768)
+static __device__ __align__(256) float g_scale_cast_scratch[SCALE_CAST_SCRATCH_BYTES / sizeof(float)];
+#define SCRATCH_MAX_DEVICES 64
+static float* g_scale_cast_scratch_ptr[SCRATCH_MAX_DEVICES];
+static std::mutex g_scale_cast_scratch_lock;
+
+static int scale_cast_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SCRATCH_MAX_DEVICES) {
+        getmi_set_error("scale_cast_noalloc: no current HIP device (or device index %d >= %d)", dev, SCRATCH_MAX_DEVICES);
+        return GETMI_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> guard(g_scale_cast_scratch_lock);
+    if (g_scale_cast_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_scale_cast_scratch));
+        if (e != hipSuccess || p == nullptr) {
+            getmi_set_error("scale_cast_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return GETMI_ERR_LAUNCH;
+        }
+        g_scale_cast_scratch_ptr[dev] = reinterpret_cast<float*>(p);
+    }
+    *out = g_scale_cast_scratch_ptr[dev];
+    return GETMI_OK;
+}
+
+size_t getmi_scale_cast_noalloc_max_bytes_impl(void) { return SCALE_CAST_SCRATCH_BYTES; }
+
+int getmi_scale_cast_noalloc_impl(const float* dx, const float* rowscale, int rows_per_sample, bf16_t* dz, float* dbias,
+                                  int accumulate, int M, int D, hipStream_t st) {
+    GETMI_CHECK_ARG(D == 768 || D == 256 || D == 512 || D == 1024, "scale_cast_noalloc: D=%d unsupported", D);
+    GETMI_CHECK_ARG(M > 0, "scale_cast_noalloc: M=%d", M);
+    const size_t need = getmi_scale_cast_workspace_bytes_impl(M, D);
+    GETMI_CHECK_ARG(need <= SCALE_CAST_SCRATCH_BYTES,
+                    "scale_cast_noalloc: M=%d x D=%d needs %zu bytes of scratch, the built-in buffer holds %u "
+                    "(use getmi_scale_cast with a caller workspace)", M, D, need, SCALE_CAST_SCRATCH_BYTES);
+    float* scratch = nullptr;
+    if (int rc = scale_cast_scratch(&scratch)) return rc;
+    // every partial row the reduction reads is written by this call's first kernel: nothing has to start at zero
+    return getmi_scale_cast_impl(dx, rowscale, rows_per_sample, dz, dbias, accumulate, M, D, scratch, SCALE_CAST_SCRATCH_BYTES, st);
 }
 
 int getmi_head_fwd_impl(const bf16_t* hf, const float* W, const float* bias, float* logits, float* pred, int B, int N,

@@ -296,3 +296,14 @@ def colsum_bf16(X, M=None):
     ws = _ws(lib.query("getmi_colsum_workspace_bytes", N), X.device)
     lib.call("getmi_colsum_bf16", X, out, 0, M, N, X.stride(0), ws, ws.numel())
     return out
+
+
+def scale_cast_noalloc(dx, rowscale=None, rows_per_sample=0):
+    """scale_cast through the entry point that uses the library's built-in scratch buffer (no workspace argument; for
+    callers that cannot allocate).  The two result tensors here are the caller's outputs, as in the C ABI."""
+    _chk(dx, rowscale)
+    M, D = dx.shape
+    dz = torch.empty(M, D, dtype=BF16, device=dx.device)
+    dbias = torch.empty(D, dtype=F32, device=dx.device)
+    lib.call("getmi_scale_cast_noalloc", dx, rowscale, rows_per_sample, dz, dbias, 0, M, D)
+    return dz, dbias

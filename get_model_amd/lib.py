@@ -43,6 +43,8 @@ _SIGNATURES = {
     "getmi_scale_by_scalar": (_i, [_vp, _vp, _f, _vp, _i64, _vp]),
     "getmi_scale_cast_workspace_bytes": (_sz, [_i, _i]),
     "getmi_scale_cast": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "getmi_scale_cast_noalloc_max_bytes": (_sz, []),
+    "getmi_scale_cast_noalloc": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "getmi_gather_rows_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "getmi_mask_compact": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "getmi_colsum_workspace_bytes": (_sz, [_i]),

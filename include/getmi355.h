@@ -119,6 +119,16 @@ size_t getmi_scale_cast_workspace_bytes(int M, int D);
 int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample, void* dz_bf16, float* dbias,
                      int accumulate, int M, int D, void* workspace, size_t workspace_bytes, void* stream);
 
+/* No counterpart in the reference.  getmi_scale_cast for callers that CANNOT allocate or hand over a workspace (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same kernels, same results, the
+ * column-sum partials live in a 3 MiB device buffer built into the library (one copy per GPU, held until the process
+ * ends).  Calls no hipMalloc / hipFree or other allocating routine.  Shapes whose getmi_scale_cast_workspace_bytes(M, D)
+ * exceeds getmi_scale_cast_noalloc_max_bytes() are rejected (e.g. D = 1024 with M > 3072).  Every call on a GPU
+ * shares that GPU's buffer: calls that overlap on one GPU (two streams, two threads) race. */
+size_t getmi_scale_cast_noalloc_max_bytes(void);
+int getmi_scale_cast_noalloc(const float* dx, const float* rowscale, int rows_per_sample, void* dz_bf16, float* dbias,
+                             int accumulate, int M, int D, void* stream);
+
 /* ---- masked-row gather/scatter (model/model.py:527,535), column sums (bias gradients) ----------- */
 int getmi_gather_rows_bf16(const void* src, const int64_t* idx, void* dst, int n, int D, int scatter,
                            void* stream);
