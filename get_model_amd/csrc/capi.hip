@@ -8,6 +8,14 @@ struct GemmArgs {
     const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0;
 };
 int getmi_gemm_tn_colsum_rows(int M, int N);
+int getmi_gemm_tn_colsum_rows_max(int M, int N);
+int getmi_cu_scope_enter(int all_cus);
+void getmi_cu_scope_leave(int token);
+struct CuScope {     // one CU-budget snapshot per C-ABI call (see gemm.hip)
+    int token;
+    explicit CuScope(bool all_cus) : token(getmi_cu_scope_enter(all_cus ? 1 : 0)) {}
+    ~CuScope() { getmi_cu_scope_leave(token); }
+};
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
                          hipStream_t st);
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st);
@@ -70,21 +78,22 @@ int getmi_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, voi
 int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, void* stream) {
     return getmi_qkv_bias_impl(q_bias, v_bias, out, D, ST(stream));
 }
-size_t getmi_gemm_tn_workspace_bytes(int M, int N) { return (size_t)getmi_gemm_tn_colsum_rows(M, N) * N * sizeof(float); }
+size_t getmi_gemm_tn_workspace_bytes(int M, int N) { return (size_t)getmi_gemm_tn_colsum_rows_max(M, N) * N * sizeof(float); }
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0, void* out1,
                   int ldo, const float* bias, const float* resid, const float* rowscale, int rows_per_sample,
                   const void* aux, int ldaux, const uint8_t* mask, const float* mask_token, int regions_per_sample,
                   float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    CuScope scope(false);      // tile choice, partial-row count and launch all see one CU budget
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
                mask, mask_token, regions_per_sample, nullptr, 0};
     if (dbias) {
         GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
-        GETMI_CHECK_ARG(workspace && workspace_bytes >= getmi_gemm_tn_workspace_bytes(M, N) &&
-                            ((uintptr_t)workspace % 16 == 0),
+        const size_t need = (size_t)getmi_gemm_tn_colsum_rows(M, N) * N * sizeof(float);   // <= the public query's answer
+        GETMI_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
                         "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");
         a.colsum = reinterpret_cast<float*>(workspace);
         // kernels write one partial row per (tile, wave-row[, half]); rows a variant does not use must read as zero
-        if (hipMemsetAsync(workspace, 0, getmi_gemm_tn_workspace_bytes(M, N), ST(stream)) != hipSuccess) {
+        if (hipMemsetAsync(workspace, 0, need, ST(stream)) != hipSuccess) {
             getmi_set_error("gemm_tn: workspace memset failed");
             return GETMI_ERR_LAUNCH;
         }
@@ -94,10 +103,12 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
     return 0;
 }
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2) {
+    CuScope scope(true);       // sized for all CUs: an upper bound under any getmi_set_cu_limit
     return (size_t)getmi_wgrad_nsplit(M, N1, N2) * N1 * N2 * sizeof(float);
 }
 int getmi_gemm_wgrad(const void* X, const void* Y, int M, int N1, int N2, int ldx, int ldy, float* out, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream) {
+    CuScope scope(false);
     return getmi_gemm_wgrad_impl(BF(X), BF(Y), M, N1, N2, ldx, ldy, out, accumulate, reinterpret_cast<float*>(workspace),
                                  workspace_bytes, ST(stream));
 }
@@ -182,11 +193,13 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
 }
 
 size_t getmi_gemm_wgrad_pair_workspace_bytes(int M, int N1a, int N2a, int N1b, int N2b) {
+    CuScope scope(true);
     return getmi_wgrad_pair_workspace_bytes(M, N1a, N2a, N1b, N2b);
 }
 int getmi_gemm_wgrad_pair(const void* Xa, const void* Ya, int N1a, int N2a, int ldxa, int ldya, float* outa, int accumulate_a,
                           const void* Xb, const void* Yb, int N1b, int N2b, int ldxb, int ldyb, float* outb, int accumulate_b,
                           int M, void* workspace, size_t workspace_bytes, void* stream) {
+    CuScope scope(false);
     return getmi_gemm_wgrad_pair_impl(BF(Xa), BF(Ya), N1a, N2a, ldxa, ldya, outa, accumulate_a, BF(Xb), BF(Yb), N1b, N2b, ldxb,
                                       ldyb, outb, accumulate_b, M, reinterpret_cast<float*>(workspace), workspace_bytes,
                                       ST(stream));

@@ -15,6 +15,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 
 enum {
     EPI_BF16 = 0,         // out0(bf16) = acc (+bias)
@@ -1335,24 +1336,41 @@ static bool use_big_tile(const GemmArgs& a) {
 // RCCL's channel workgroups while a gradient all-reduce overlaps backward -- cannot take one, and with a grid
 // equal to the CU count the displaced workgroups run as a SECOND round (2x kernel time).  getmi_set_cu_limit(n)
 // shrinks the grids to n so that cannot happen; ddp.autotune measures whether it pays.
-static int g_num_cu = 0;
-static int g_cu_limit = 0;
-static int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0, n = 0;
+static std::atomic<int> g_num_cu{0};
+static std::atomic<int> g_cu_limit{0};
+// One C-ABI call = one value of the CU budget: an entry point takes a snapshot when it starts (cu_scope_enter) and every
+// grid size, split count and workspace layout inside that call uses the snapshot, so a getmi_set_cu_limit from another
+// thread (ddp.GradBuckets flips it from the autograd thread while the main thread may be in forward) can never make the
+// query, the check and the launch of one call disagree.  The *_workspace_bytes queries always answer for ALL CUs, which
+// is an upper bound for every limit (fewer CUs -> fewer M-splits), so a buffer sized before a change still fits after it.
+static thread_local int t_cu_snapshot = 0;
+static int total_cu() {
+    int n = g_num_cu.load(std::memory_order_relaxed);
+    if (n == 0) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
-        g_num_cu = n;
+        g_num_cu.store(n, std::memory_order_relaxed);
     }
-    return (g_cu_limit > 0 && g_cu_limit < g_num_cu) ? g_cu_limit : g_num_cu;
+    return n;
 }
-int getmi_set_cu_limit_impl(int n) {
-    const int prev = g_cu_limit;
-    g_cu_limit = n > 0 ? n : 0;
-    return prev;
+static int limited_cu() {
+    const int n = total_cu(), lim = g_cu_limit.load(std::memory_order_relaxed);
+    return (lim > 0 && lim < n) ? lim : n;
 }
-int getmi_cu_count_impl() { return num_cu(); }
+static int num_cu() { return t_cu_snapshot > 0 ? t_cu_snapshot : limited_cu(); }
+// -> token for cu_scope_leave.  all_cus: snapshot the unlimited count (workspace queries).  Nested scopes keep the outer one.
+int getmi_cu_scope_enter(int all_cus) {
+    if (t_cu_snapshot > 0) return -1;
+    t_cu_snapshot = all_cus ? total_cu() : limited_cu();
+    return 0;
+}
+void getmi_cu_scope_leave(int token) {
+    if (token == 0) t_cu_snapshot = 0;
+}
+int getmi_set_cu_limit_impl(int n) { return g_cu_limit.exchange(n > 0 ? n : 0, std::memory_order_relaxed); }
+int getmi_cu_count_impl() { return limited_cu(); }
 
 // Tile height of the 8-wave kernels for an M x N problem: 224 rows (RB1 = 3) when the rounds the CUs need, weighted by
 // the tile height, come out shorter than with 256 rows (RB1 = 4) even after charging the short tile 6 % (same
@@ -1505,13 +1523,21 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
     return GETMI_OK;
 }
 
-// number of partial rows the DGELU column-sum epilogue writes for this problem (depends on the tile choice)
+// number of partial rows the DGELU column-sum epilogue writes for this problem (depends on the tile choice, which
+// depends on the CU budget of the running call)
 int getmi_gemm_tn_colsum_rows(int M, int N) {
     GemmArgs a{};
     a.M = M; a.N = N;
     if (!use_big_tile(a)) return ((M + 127) / 128) * 2;
     const int bm = pick_rb1(M, N) == 3 ? 224 : 256;
     return ((M + bm - 1) / bm) * 4;
+}
+// ... and its upper bound over every tile choice (what a workspace must hold whatever the CU limit is at launch time)
+int getmi_gemm_tn_colsum_rows_max(int M, int N) {
+    GemmArgs a{};
+    a.M = M; a.N = N;
+    if (!use_big_tile(a)) return ((M + 127) / 128) * 2;
+    return ((M + 223) / 224) * 4;
 }
 
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {

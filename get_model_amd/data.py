@@ -114,6 +114,9 @@ class RegionMotifDataset:
     def __init__(self, stores, celltypes=None, quantitative_atac=False, sampling_step=50, num_region_per_sample=1000,
                  leave_out_chromosomes=None, leave_out_celltypes=None, is_train=True, mask_ratio=0.0,
                  drop_zero_atpm=True, seed=None):
+        """seed: None / int -> a private numpy Generator (reproducible per data set); "numpy-global" -> numpy's global
+        stream through the reference's own calls (np.random.randint in setup, np.random.choice per item), which
+        reproduces the reference's windows and masks draw for draw under the same np.random.seed (the parity tests)."""
         stores = stores if isinstance(stores, (list, tuple)) else [stores]
         available = []
         for st in stores:
@@ -127,7 +130,7 @@ class RegionMotifDataset:
         leave_ct = leave_out_celltypes.split(",") if leave_out_celltypes else []
         self.is_train = is_train
         self.mask_ratio = mask_ratio
-        self.rng = np.random.default_rng(seed)
+        self.rng = None if seed == "numpy-global" else np.random.default_rng(seed)
         self.region_motifs = {}
         for ct in self.celltypes:
             if leave_ct and ((is_train and ct in leave_ct) or (not is_train and ct not in leave_ct)):
@@ -145,8 +148,11 @@ class RegionMotifDataset:
                 idx = np.nonzero(rm.chromosome == chrom)[0]
                 if len(idx) == 0:
                     continue
-                for i in range(idx[0], idx[-1], step):
-                    shift = int(self.rng.integers(-step // 2, step // 2))
+                # the reference walks the ORIGINAL row labels of the chromosome's first / last kept peak (its DataFrame keeps
+                # the pre-drop index, zarr_dataset.py:912,1095-1099) and then uses them as positions in the kept table
+                for i in range(int(rm.kept_index[idx[0]]), int(rm.kept_index[idx[-1]]), step):
+                    shift = int(np.random.randint(-step // 2, step // 2) if self.rng is None
+                                else self.rng.integers(-step // 2, step // 2))
                     start = max(0, i + shift)
                     end = start + n
                     if end >= rm.num_peaks:
@@ -169,8 +175,11 @@ class RegionMotifDataset:
         else:
             pos = neg = tss = np.zeros(e - s)
         col = atpm.reshape(-1, 1) / atpm.max() if self.quantitative_atac else np.ones((e - s, 1))
-        mask = self.rng.choice([0, 1], size=len(tss), p=[1 - self.mask_ratio, self.mask_ratio]) \
-            if self.mask_ratio > 0 else tss
+        if self.mask_ratio > 0:
+            draw = np.random.choice if self.rng is None else self.rng.choice
+            mask = draw([0, 1], size=len(tss), p=[1 - self.mask_ratio, self.mask_ratio])
+        else:
+            mask = tss
         return {"region_motif": np.concatenate([motif, col], axis=1).astype(np.float32), "mask": mask,
                 "atpm": atpm.reshape(-1, 1), "chromosome": rm.chromosome[s],
                 "peak_coord": np.stack([rm.start[s:e], rm.end[s:e]], 1),

@@ -13,7 +13,8 @@
  *    getmi_last_error() (thread-local).  No exceptions, no exit().
  *  - the library never allocates device memory: scratch comes in through (workspace, workspace_bytes),
  *    sized by the matching *_workspace_bytes() query.  Workspaces must be 256-byte aligned.
- *  - re-entrant; no mutable global state besides one-time kernel attribute set-up.
+ *  - re-entrant.  Global state: one-time kernel attribute set-up and environment switches (idempotent), the atomic CU
+ *    limit of getmi_set_cu_limit (read once per call), and the per-GPU scratch address of getmi_scale_cast_noalloc.
  */
 #ifndef GETMI355_H
 #define GETMI355_H
@@ -152,8 +153,11 @@ int getmi_gemm_wgrad_pair(const void* Xa, const void* Ya, int N1a, int N2a, int 
  *      libraries).  The persistent GEMM and the weight-gradient GEMM launch one workgroup per CU, each taking the
  *      whole CU; while RCCL's channel workgroups are resident (gradient all-reduce overlapped with backward) some
  *      CUs cannot host them and the displaced workgroups would run as a second round.  getmi_set_cu_limit(n) makes
- *      those kernels size their grids for n CUs (0 = all CUs again) and returns the previous limit; process-wide,
- *      takes effect at the next launch.  getmi_cu_count() = the CU count currently assumed. */
+ *      those kernels size their grids for n CUs (0 = all CUs again) and returns the previous limit; process-wide and
+ *      atomic.  Every entry point reads the limit ONCE when it is called, so a change from another thread never splits
+ *      one call; the *_workspace_bytes queries always answer for all CUs (an upper bound under any limit), so a
+ *      workspace sized before a change is still large enough after it.  getmi_cu_count() = the CU count the next call
+ *      will assume. */
 int getmi_set_cu_limit(int n);
 int getmi_cu_count(void);
 

@@ -98,3 +98,59 @@ def test_producer_feeds_the_model_on_the_gpu():
     loss = model.after_loss(model.loss(pred, obs))
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+import glob
+import os
+
+import pytest
+
+EXTRA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_extra")
+_STORE_KW = {
+    "data_two_celltypes": (dict(num_peaks=3000, celltypes=("a", "b"), seed=2),
+                           dict(celltypes="a,b", sampling_step=50, num_region_per_sample=200, quantitative_atac=True)),
+    "data_leave_out_chr": (dict(num_peaks=2400, celltypes=("a",), seed=6, chromosomes=("chr1", "chr2", "chr3")),
+                           dict(celltypes="a", sampling_step=40, num_region_per_sample=100, leave_out_chromosomes="chr2",
+                                is_train=True)),
+    "data_eval_split_pretrain_mask": (dict(num_peaks=2400, celltypes=("a",), seed=6, chromosomes=("chr1", "chr2", "chr3")),
+                                      dict(celltypes="a", sampling_step=40, num_region_per_sample=100,
+                                           leave_out_chromosomes="chr2", is_train=False, mask_ratio=0.5)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_STORE_KW))
+def test_dataset_equals_the_reference_dataset(name):
+    """Fixtures = the reference's own RegionMotif / RegionMotifDataset (zarr_dataset.py:880-1185) run on the synthetic
+    store (oracle/make_golden_data.py: zarr replaced by an in-memory group, everything else reference code): the same
+    windows in the same order, the same normalisation, the same items, draw for draw under the same numpy seed."""
+    z = np.load(os.path.join(EXTRA, name + ".npz"), allow_pickle=False)
+    skw, dkw = _STORE_KW[name]
+    st = D.make_synthetic_store(**skw)
+    np.random.seed(int(z["seed"]))
+    ds = D.RegionMotifDataset(st, seed="numpy-global", **dkw)
+    cts = [str(c) for c in z["celltypes"]]
+    assert list(ds.region_motifs) == cts
+    assert len(ds) == int(z["n_samples"])
+    got = [(cts.index(c), s, e) for c, s, e in ds.sample_indices]
+    assert got == list(zip(z["sample_ct"].tolist(), z["sample_start"].tolist(), z["sample_end"].tolist()))
+    for ct, rm in ds.region_motifs.items():
+        assert np.array_equal(np.asarray(rm.normalizing_factor, dtype=np.float64), z[f"norm_factor/{ct}"])
+        nd = rm.normalized_data
+        chk = np.array([nd.shape[0], nd.sum(dtype=np.float64), (nd.astype(np.float64) ** 2).sum()])
+        assert np.array_equal(chk, z[f"norm_chk/{ct}"])
+        assert np.array_equal(np.array([rm.expression_positive.sum(dtype=np.float64),
+                                        rm.expression_negative.sum(dtype=np.float64)]), z[f"exp_chk/{ct}"])
+    for j, i in enumerate(z["item_ids"].tolist()):
+        it = ds[i]
+        for key in ("region_motif", "exp_label", "mask", "atpm", "peak_coord"):
+            assert np.array_equal(np.asarray(it[key]), z[f"item{j}/{key}"]), (i, key)
+        assert it["region_motif"].dtype == np.float32 and it["exp_label"].dtype == np.float32
+        assert str(it["chromosome"]) == str(z[f"item{j}/chromosome"]) and it["celltype"] == str(z[f"item{j}/celltype"])
+    # ... and the device-side batch gather gives exactly these items (deterministic keys)
+    if dkw.get("mask_ratio", 0) == 0:
+        prod = D.RegionBatchProducer(ds, batch_size=3, device="cpu", shuffle=False)
+        batch = prod.gather(z["item_ids"].tolist())
+        for j in range(3):
+            assert np.allclose(batch["region_motif"][j].numpy(), z[f"item{j}/region_motif"], rtol=0, atol=1e-6)
+            assert np.array_equal(batch["exp_label"][j].numpy(), z[f"item{j}/exp_label"])
+            assert np.array_equal(batch["mask"][j].numpy(), z[f"item{j}/mask"])

@@ -67,6 +67,15 @@ def _worker(rank, world, port, out_path):
         step_fn()
         for n, p in m.named_parameters():
             assert torch.allclose(p.grad, grads[n], atol=1e-7), (n, mode)
+    # a training loop that only knows optimizer.zero_grad(): finish() must have re-armed the bucket bookkeeping, or no
+    # bucket would be exchanged again and the ranks would silently diverge
+    gb.overlap = True
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        ((m(xs) - ys) ** 2).mean().backward()
+        gb.finish()
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.grad, grads[n], atol=1e-7), n
     if rank == 0:
         torch.save(({n: p.detach().clone() for n, p in m.named_parameters()}, grads, x, y), out_path)
     dist.barrier()

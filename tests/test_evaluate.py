@@ -73,3 +73,24 @@ def test_validation_step_tss_masking_and_early_outs():
     assert E.validation_step(_Toy(pred * float("nan")), {"exp_label": obs, "mask": mask})[1] is None    # NaN
     _, met_all = E.validation_step(m, {"exp_label": obs, "mask": mask}, eval_tss=False)
     assert met_all is not None
+
+
+def test_spearman_uses_average_ranks_for_ties():
+    """torchmetrics SpearmanCorrCoef (model/model.py:173-174) ranks ties by the mean of their positions; expression
+    labels are mostly tied zeros.  torchmetrics is not installed here: scipy.stats.spearmanr has the same definition."""
+    import numpy as np
+    from scipy.stats import rankdata, spearmanr
+    from get_model_amd.model.model import RegressionMetrics
+    g = torch.Generator().manual_seed(4)
+    obs = torch.rand(500, generator=g) * 4
+    obs[torch.rand(500, generator=g) < 0.7] = 0.0                 # 70 % tied zeros
+    obs[10:20] = 1.5                                              # and a second run of ties
+    pred = (obs + 0.3 * torch.randn(500, generator=g)).clamp_min(0).round(decimals=1)     # ties in pred too
+    r = RegressionMetrics._rank(obs)
+    assert np.array_equal(r.numpy(), rankdata(obs.numpy()).astype(np.float32))
+    m = RegressionMetrics({"components": {"exp": ["spearman", "pearson"]}})
+    got = float(m({"exp": pred}, {"exp": obs})["exp_spearman"])
+    assert abs(got - spearmanr(pred.numpy(), obs.numpy()).statistic) < 1e-5
+    # order independence (argsort-of-argsort ranks depended on the order of the tied elements)
+    perm = torch.randperm(500, generator=g)
+    assert abs(float(m({"exp": pred[perm]}, {"exp": obs[perm]})["exp_spearman"]) - got) < 1e-6

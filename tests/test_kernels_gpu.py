@@ -367,3 +367,34 @@ def test_gemm_wgrad_pair_equals_two_calls(K):
         ra, rb_ = Xa.float().t() @ Ya.float(), Xb.float().t() @ Yb.float()
         close(oa, ra, 1e-4, 1e-3 * math.sqrt(M), "pair.a")
         close(ob, rb_, 1e-4, 1e-3 * math.sqrt(M), "pair.b")
+
+
+def test_cu_limit_is_read_once_per_call_and_workspaces_stay_valid(K):
+    """getmi_set_cu_limit (ddp: CUs left to RCCL while an all-reduce overlaps backward): results do not depend on the
+    limit, and a workspace sized under one limit is large enough under any other (queries answer for all CUs)."""
+    from get_model_amd import lib
+    M, N1, N2 = 8192 + 40, 768, 768
+    g = torch.Generator(device="cpu").manual_seed(9)
+    X = (torch.randn(M, N1, generator=g) * 0.5).bfloat16().cuda()
+    Y = (torch.randn(M, N2, generator=g) * 0.5).bfloat16().cuda()
+    total = lib.query("getmi_cu_count")
+    ref = K.gemm_wgrad(X, Y)
+    try:
+        sizes = set()
+        for lim in (0, total - 16, total // 2, 64):
+            lib.query("getmi_set_cu_limit", lim)
+            assert lib.query("getmi_cu_count") == (lim if lim else total)
+            sizes.add(lib.query("getmi_gemm_wgrad_workspace_bytes", M, N1, N2))
+            out = K.gemm_wgrad(X, Y)
+            torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-3)
+            # fused column sums of the dGELU-form GEMM: the partial-row layout follows the tile choice of THIS call
+            A = (torch.randn(4096, 768, generator=g) * 0.5).bfloat16().cuda()
+            W = (torch.randn(1024, 768, generator=g) * 0.05).bfloat16().cuda()
+            aux = torch.ones(4096, 1024, dtype=torch.bfloat16, device="cuda")
+            o = torch.empty(4096, 1024, dtype=torch.bfloat16, device="cuda")
+            db = torch.empty(1024, device="cuda")
+            K.gemm_tn(K.EPI_DMUL, A, W, o, aux=aux, dbias=db)
+            torch.testing.assert_close(db, (A.float() @ W.float().t()).sum(0), rtol=2e-2, atol=0.5)
+        assert len(sizes) == 1
+    finally:
+        lib.query("getmi_set_cu_limit", 0)
