@@ -88,7 +88,8 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
                mask, mask_token, regions_per_sample, nullptr, 0};
     if (dbias) {
         GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
-        const size_t need = (size_t)getmi_gemm_tn_colsum_rows(M, N) * N * sizeof(float);   // <= the public query's answer
+        // partial rows for ANY tile height the launcher may pick (rows a variant does not write stay zero and add nothing)
+        const size_t need = getmi_gemm_tn_workspace_bytes(M, N);
         GETMI_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
                         "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");
         a.colsum = reinterpret_cast<float*>(workspace);
@@ -99,7 +100,7 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
         }
     }
     if (int rc = getmi_gemm_tn_impl(epi, a, ST(stream))) return rc;
-    if (dbias) return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, getmi_gemm_tn_colsum_rows(M, N), N, 0, ST(stream));
+    if (dbias) return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, getmi_gemm_tn_colsum_rows_max(M, N), N, 0, ST(stream));
     return 0;
 }
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2) {

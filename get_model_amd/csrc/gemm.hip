@@ -711,8 +711,42 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
     }
 }
 
+// Which output tiles a persistent workgroup walks, and in which order.
+// Logical tile order = column-group major: the N-tiles are cut into groups of `group_n` columns, and inside a group the
+// order is row-block major (tm, then the group's columns).  XCD x (the workgroups with equal blockIdx % 8, made contiguous
+// by xcd_remap) takes the x-th EIGHTH of that order for the whole launch, its workgroups striding through it together.
+// So at any time the 32 workgroups of an XCD share a few row blocks of A and at most group_n column blocks of B, and
+// those B blocks stay in the XCD's 4 MiB L2 from round to round (the host picks group_n so that they fit): with plain
+// row-major rounds dealt across the XCDs every XCD re-fetched ALL of B every round (fc1: 12 blocks = 4.7 MB > L2;
+// rocprofv3 FETCH_SIZE 448 MB per launch for 84 MB of operands).  group_n == 0 or a grid that is not a multiple of 8:
+// the old round-robin order.
+struct TileWalk {
+    int first, stride, count, tiles_m, tiles_n, group_n;
+    __device__ __forceinline__ void init(int bslot, int G, int ntiles, int tm_, int tn_, int gn_) {
+        tiles_m = tm_; tiles_n = tn_;
+        if (gn_ > 0 && (G & 7) == 0) {
+            group_n = gn_;
+            const int q = G >> 3, x = bslot / q, c = bslot - x * q;
+            const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+            first = lo + c; stride = q; count = (hi - lo - c + q - 1) / q;      // >= 1: hi - lo >= q because ntiles >= G
+        } else {
+            group_n = tn_;
+            first = bslot; stride = G; count = (ntiles - bslot + G - 1) / G;
+        }
+    }
+    // tile i of this workgroup (i clamped to the last one: look-ahead past the end re-stages the last tile, never used)
+    __device__ __forceinline__ void decode(int i, int& tm, int& tn) const {
+        const int lid = first + min(i, count - 1) * stride;
+        const int per = tiles_m * group_n;
+        const int cg = lid / per, rem = lid - cg * per;
+        const int w = min(group_n, tiles_n - cg * group_n);
+        tm = rem / w;
+        tn = cg * group_n + (rem - tm * w);
+    }
+};
+
 template <int EPI, int RB1>      // RB1: see gemm_tn256_kernel (4 = 256-row tiles, 3 = 224-row tiles)
-__global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int ntiles) {
+__global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int ntiles, int group_n, int skew) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int E = EpiStores<EPI, RB1>::value;
     constexpr int BMv = 128 + 32 * RB1, HW = BMv / 2;
@@ -723,7 +757,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     const int bslot = xcd_remap(blockIdx.x, G);
     const int tiles_n = (p.N + 255) >> 8;
     const int nk = p.K >> 6;                                    // >= 2 (host-checked)
-    const int ntl = (ntiles - bslot + G - 1) / G;               // tiles of this workgroup (>= 1: G <= ntiles)
+    TileWalk walk;
+    walk.init(bslot, G, ntiles, (p.M + BMv - 1) / BMv, tiles_n, group_n);
+    const int ntl = walk.count;                                 // tiles of this workgroup (>= 1: G <= ntiles)
     const int Gk = ntl * nk;                                    // K-tiles of this workgroup's stream
     const int Q = Gk << 2;                                      // half-tiles of the stream
 
@@ -739,8 +775,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     unsigned cur[4][2], nxt[4][2];
     int dst[4][2];
     auto tile_offsets = [&](int it, unsigned (&o)[4][2]) {
-        const int lid = min(it * G + bslot, ntiles - 1);
-        const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+        int tm, tn;
+        walk.decode(it, tm, tn);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -803,13 +839,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     char* bias_img = smem + G2_LDS;                      // 1 KiB shared image: every wave DMA-writes the same values
     char* stage = smem + G2_LDS + 1024 + wave * 2048;    // 2 KiB wave-private store stage
     auto stage_bias = [&](int iter) {
-        const int lid = min(iter * G + bslot, ntiles - 1);
-        const int tn = lid % tiles_n;
+        int tm, tn;
+        walk.decode(iter, tm, tn);
         glds16(p.bias + min((tn << 8) + lane * 4, p.N - 4), bias_img);
     };
     if (has_bias) stage_bias(0);
     GP_ISSUE(0, 0); GP_ISSUE(0, 1); GP_ISSUE(0, 2); GP_ISSUE(0, 3);
     GP_ISSUE(1, 0); GP_ISSUE(1, 1); GP_ISSUE(1, 2);              // Gk >= 2
+    // De-synchronise the CUs (see launch_gemm_tn256p): workgroup b starts up to `skew` x 2048 cycles late, spread evenly
+    // over the grid by a bit-reversal-like stride so that neighbours in an XCD differ.
+    if (skew > 0) {
+        const int n = (int)(((unsigned)(bslot * 97) % (unsigned)G) * (unsigned)skew / (unsigned)G);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
 
     // Fragment reads are inline asm with COUNTED lgkmcnt waits: hipcc clusters the ds_reads of a phase and puts one
     // `s_waitcnt lgkmcnt(0)` in front of the first MFMA, which serialises the phase (all eight waves read LDS, then
@@ -916,8 +958,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
         for (; k < nk; ++k) ktile(tile_g0 + k, std::false_type{});
         {
             // ---- tile finished: epilogue (its stores drain under the next tile), then switch tiles ----
-            const int lid = it * G + bslot;
-            const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+            int tm, tn;
+            walk.decode(it, tm, tn);
             const float* bl = has_bias ? reinterpret_cast<const float*>(bias_img) + wn * 64 + (lane >> 4) * 4 : nullptr;
             epilogue_p<EPI, RB1>(p, acc, tm * BMv + wm * HW, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
 #pragma unroll
@@ -944,6 +986,264 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
 #undef GP_MM
 #undef GP_MM4
 #undef GP_WAIT
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn, second generation ("two workgroups per CU"): 256 x 128 output tile per workgroup of FOUR waves (2 M x 2 N,
+// 128 x 64 per wave -- the same per-wave block, fragment reads and MFMA order as the 256 x 256 kernels), persistent,
+// 73 KiB of LDS and <= 256 VGPRs, so that TWO workgroups are resident on every CU and run unsynchronised: while one is
+// in its epilogue (GELU arithmetic, the stored-derivative or fp32-residual reads: phases a single resident workgroup
+// WAITS for) or at a barrier, the other one's MFMAs have the matrix pipes to themselves.  The
+// price is 1.5 x the operand traffic L2 -> LDS per FLOP of the 256 x 256 tile; the gain is measured per shape
+// (tools/bench_gemm.py) and the launcher keeps whichever generation is faster there.
+//
+// Operands per K-tile (64 deep): three 16-KiB PIECES of 128 rows x 128 B -- A0 (rows 0-63 of both wave rows), B (all
+// 128 columns), A1 (rows 64-127 of both wave rows) -- streamed in that order through a ring of FOUR slots (piece q =
+// 3 g + j of stream K-tile g lives in slot q & 3), one piece issued per barrier:
+//     P1  wait A0(g), B(g)  | barrier | issue A0(g+1) -> slot of A1(g-1) | read A0, B-low  | 16 MFMA  A0 x B-low
+//     P2                    | barrier | issue B(g+1)  -> slot of A0(g)   | read B-high     | 16 MFMA  A0 x B-high
+//     P3  wait A1(g)        | barrier | issue A1(g+1) -> slot of B(g)    | read A1         | 16 MFMA  A1 x B-high
+//     P4                                                                                   | 16 MFMA  A1 x B-low
+// RAW: every wave waits for its own share of a piece (counted vmcnt: 4 LDS-DMA per piece and wave; pieces younger than
+// the needed one stay in flight: A1(g) at P1, A0(g+1) + B(g+1) at P3) before the barrier in front of the reads.
+// WAR: a slot is re-issued only after a barrier that every wave reaches after its last fragment read of the old piece
+// has been consumed by MFMAs (A1(g-1): read in P3(g-1); A0(g): read in P1(g); B(g): last read in P2(g)).
+// The epilogue's stores (E per wave, exact: inline asm) and the next tile's bias DMA are issued between A1(n0) and
+// A0(n1) of the next output tile's first K-tiles, so that tile's two waits count them in: vmcnt(4 + EB), vmcnt(8 + EB).
+// ------------------------------------------------------------------------------------------------
+#define G3_RING 65536
+#define G3_LDS (G3_RING + 2048 + 4 * 2048)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmArgs p, int ntiles, int group_n, int stagger) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = EpiStores<EPI, 4>::value;
+    constexpr int EB = E + (EpiKind<EPI>::dgelu ? 0 : 1);       // + the bias row DMA of the next tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x;
+    const int bslot = xcd_remap(blockIdx.x, G);
+    const int tiles_n = (p.N + 127) >> 7;
+    const int nk = p.K >> 6;                                    // >= 2 (host-checked)
+    TileWalk walk;
+    walk.init(bslot, G, ntiles, (p.M + 255) >> 8, tiles_n, group_n);
+    const int ntl = walk.count;                                 // tiles of this workgroup (>= 1: G <= ntiles)
+
+    const unsigned esz = (EPI == EPI_BIAS_RESID) ? 4u : 2u;
+    const u32x4 rs0 = make_rsrc(p.out0 ? p.out0 : p.out1, p.out0 ? (unsigned)((size_t)p.M * p.ldo * esz) : 0u);
+    const u32x4 rs1 = make_rsrc(p.out1 ? p.out1 : p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
+    const u32x4 rsc = make_rsrc(p.colsum ? (const void*)p.colsum : (const void*)p.out0,
+                                p.colsum ? (unsigned)((size_t)((p.M + 255) >> 8) * 4 * p.N * 4) : 0u);
+
+    // ---- staging: LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds).  The per-lane byte offsets
+    //      are the SAME for every output tile (row of the piece image x leading dimension + swizzled 16-B chunk); the
+    //      tile enters through the descriptor (base = first row of the tile, num_records = what is left of the operand
+    //      from there, so rows past M / N are dropped by the range check: no clamping arithmetic, no per-tile VGPRs) and
+    //      the K-tile through the scalar offset.  Piece kind 0 = A0, 1 = B, 2 = A1; 4 wave-instructions (8 rows) each. ----
+    unsigned vA0[4], vA1[4], vB[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int hr = (wave * 4 + jj) * 8 + (lane >> 3);                  // row of the piece image, 0..127
+        const unsigned sw = (unsigned)(((lane & 7) ^ ((hr >> 1) & 7)) << 4);
+        vA0[jj] = (unsigned)((((hr >> 6) << 7) + (hr & 63)) * p.lda * 2) + sw;
+        vA1[jj] = vA0[jj] + (unsigned)(64 * p.lda * 2);
+        vB[jj] = (unsigned)(hr * p.ldb * 2) + sw;
+    }
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto tile_rsrc = [&](int iter, rsrc_t& ra, rsrc_t& rb) {
+        int tm, tn;
+        walk.decode(iter, tm, tn);
+        const size_t rowsA = (size_t)(p.M - (tm << 8)), rowsB = (size_t)(p.N - (tn << 7));
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A) + (size_t)(tm << 8) * p.lda, 0,
+                                               (unsigned)(rowsA * p.lda * 2), 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B) + (size_t)(tn << 7) * p.ldb, 0,
+                                               (unsigned)(rowsB * p.ldb * 2), 0x00020000);
+    };
+    rsrc_t curA, curB, nxtA, nxtB;
+    tile_rsrc(0, curA, curB);
+    tile_rsrc(1, nxtA, nxtB);
+    int k_in_tile = 0;          // K-tile index inside the current output tile
+    int it = 0;                 // output tile iteration of this workgroup
+
+    // issue piece J of stream K-tile g_: K-tile kt_ of the tile whose descriptors are (RA, RB)
+#define G3_ISSUE(RA, RB, J, g_, kt_)                                                                       \
+    do {                                                                                                   \
+        char* d_ = smem + (((3 * (g_) + (J)) & 3) << 14) + (wave << 12);                                   \
+        const int koff_ = (kt_) * 128;                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds((J) == 1 ? RB : RA, LDS_PTR(d_ + jj * 1024), 16,       \
+                                                     (J) == 0 ? vA0[jj] : (J) == 1 ? vB[jj] : vA1[jj], koff_, 0, 0); \
+    } while (0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fsw = (frow >> 1) & 7;
+    const unsigned lds0 = lds_addr(smem);
+    unsigned la[2], lb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned fo = (unsigned)(frow * 128 + (((4 * ks + (lane >> 4)) ^ fsw) << 4));
+        la[ks] = lds0 + (unsigned)(wm * 64 * 128) + fo;
+        lb[ks] = lds0 + (unsigned)(wn * 64 * 128) + fo;
+    }
+
+    const bool has_bias = !EpiKind<EPI>::dgelu && p.bias != nullptr;    // workgroup-uniform
+    // bias row segment of the tile: two 1-KiB images by tile parity (every wave DMA-writes the same values; a wave that
+    // is a whole epilogue ahead must not overwrite the image its neighbours still read)
+    char* stage = smem + G3_RING + 2048 + wave * 2048;   // 2 KiB wave-private store stage
+    auto stage_bias = [&](int iter) {
+        char* bias_img = smem + G3_RING + ((iter & 1) << 10);
+        // (issued unconditionally for the epilogues that may carry a bias, so that the counted waits are compile-time
+        //  constants; without a bias the image is filled from the B operand and never read)
+        int tm, tn;
+        walk.decode(iter, tm, tn);
+        const float* src = has_bias ? p.bias + min((tn << 7) + lane * 4, p.N - 4)
+                                    : reinterpret_cast<const float*>(p.B) + lane * 4;
+        glds16(src, bias_img);
+    };
+    if constexpr (!EpiKind<EPI>::dgelu) stage_bias(0);
+    G3_ISSUE(curA, curB, 0, 0, 0); G3_ISSUE(curA, curB, 1, 0, 0); G3_ISSUE(curA, curB, 2, 0, 0);
+    // The two workgroups of a CU start together and do identical work, so left alone they reach their epilogues at the
+    // same time and nothing overlaps.  The one whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC.LDS_BASE: the
+    // second resident workgroup of its CU) starts about half an output tile late, once; the offset then persists because
+    // every tile takes both the same time.  A performance hint only: nothing depends on which workgroup waits.
+    if (stagger > 0) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6);
+        if (lds_base != 0)
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    u32x4 fa[4][2], fb0[2][2], fb1[2][2];
+#define G3_RD(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#define G3_LG1(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x) : : "memory")
+#define G3_LG2(N, x, y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y) : : "memory")
+#define G3_LG3(N, x, y, z) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x), "+v"(y), "+v"(z) : : "memory")
+#define G3_RD_A(ks, addr)                                                                                  \
+    G3_RD(fa[0][ks], addr, 0); G3_RD(fa[1][ks], addr, 2048); G3_RD(fa[2][ks], addr, 4096); G3_RD(fa[3][ks], addr, 6144);
+#define G3_RD_B(FB, NH, ks, addr) G3_RD(FB[0][ks], addr, (NH)*4096); G3_RD(FB[1][ks], addr, (NH)*4096 + 2048);
+#define G3_MM(MH, NH, FB, mt, ks)                                                                          \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                       \
+        acc[(MH)*4 + mt][(NH)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
+            __builtin_bit_cast(bf16x8, FB[nt][ks]), __builtin_bit_cast(bf16x8, fa[mt][ks]),               \
+            acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+#define G3_MM4(MH, NH, FB, ks) G3_MM(MH, NH, FB, 0, ks) G3_MM(MH, NH, FB, 1, ks) G3_MM(MH, NH, FB, 2, ks) G3_MM(MH, NH, FB, 3, ks)
+#define G3_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory")
+
+    // One K-tile.  MODE 0: first K-tile of an output tile after the first (the previous epilogue's stores + bias DMA are
+    // still counted); MODE 1: middle (everything it issues lies in the current tile); MODE 2: last K-tile of an output
+    // tile (issues the next tile's first K-tile, or nothing at the end of the stream).  MODE 3: first K-tile of the FIRST
+    // output tile (no stores outstanding) = MODE 1 waits.
+    auto ktile = [&](int g, auto mode_) {
+        constexpr int MODE = decltype(mode_)::value;
+        const unsigned q0 = (unsigned)(3 * g);
+        const unsigned sA0 = (q0 & 3u) << 14, sB = ((q0 + 1u) & 3u) << 14, sA1 = ((q0 + 2u) & 3u) << 14;
+        const bool more = (MODE != 2) || (it + 1 < ntl);      // is there a K-tile g + 1 ?
+        // ---- P1 ----
+        if constexpr (MODE == 0) G3_VM(4 + EB); else G3_VM(4);
+        phase_barrier();
+        if constexpr (MODE == 2) { if (more) G3_ISSUE(nxtA, nxtB, 0, g + 1, 0); }
+        else G3_ISSUE(curA, curB, 0, g + 1, k_in_tile + 1);
+        {
+            const unsigned a0 = la[0] + sA0, a1 = la[1] + sA0, b0 = lb[0] + sB, b1 = lb[1] + sB;
+            G3_RD_B(fb0, 0, 0, b0) G3_RD_A(0, a0) G3_RD_B(fb0, 0, 1, b1) G3_RD_A(1, a1)
+            G3_LG3(9, fb0[0][0], fb0[1][0], fa[0][0]); G3_MM(0, 0, fb0, 0, 0)
+            G3_LG1(8, fa[1][0]); G3_MM(0, 0, fb0, 1, 0)
+            G3_LG1(7, fa[2][0]); G3_MM(0, 0, fb0, 2, 0)
+            G3_LG1(6, fa[3][0]); G3_MM(0, 0, fb0, 3, 0)
+            G3_LG3(3, fb0[0][1], fb0[1][1], fa[0][1]); G3_MM(0, 0, fb0, 0, 1)
+            G3_LG1(2, fa[1][1]); G3_MM(0, 0, fb0, 1, 1)
+            G3_LG1(1, fa[2][1]); G3_MM(0, 0, fb0, 2, 1)
+            G3_LG1(0, fa[3][1]); G3_MM(0, 0, fb0, 3, 1)
+        }
+        // ---- P2 (barrier for the slot of A0(g) only) ----
+#ifndef G3_TWO_BARRIERS
+        phase_barrier();
+        if constexpr (MODE == 2) { if (more) G3_ISSUE(nxtA, nxtB, 1, g + 1, 0); }
+        else G3_ISSUE(curA, curB, 1, g + 1, k_in_tile + 1);
+#endif
+        {
+            const unsigned b0 = lb[0] + sB, b1 = lb[1] + sB;
+            G3_RD_B(fb1, 1, 0, b0) G3_RD_B(fb1, 1, 1, b1)
+            G3_LG2(2, fb1[0][0], fb1[1][0]); G3_MM4(0, 1, fb1, 0)
+            G3_LG2(0, fb1[0][1], fb1[1][1]); G3_MM4(0, 1, fb1, 1)
+        }
+        // ---- P3 ----
+#ifdef G3_TWO_BARRIERS
+        // (B(g+1) is issued here, behind the barrier: when P3 waits, only A0(g+1) is younger than A1(g))
+        if constexpr (MODE == 0) G3_VM(4 + EB);
+        else if constexpr (MODE == 2) { if (more) G3_VM(4); else G3_VM(0); }
+        else G3_VM(4);
+        phase_barrier();
+        if constexpr (MODE == 2) { if (more) G3_ISSUE(nxtA, nxtB, 1, g + 1, 0); }
+        else G3_ISSUE(curA, curB, 1, g + 1, k_in_tile + 1);
+#else
+        if constexpr (MODE == 0) G3_VM(8 + EB);
+        else if constexpr (MODE == 2) { if (more) G3_VM(8); else G3_VM(0); }
+        else G3_VM(8);
+        phase_barrier();
+#endif
+        if constexpr (MODE == 2) { if (more) G3_ISSUE(nxtA, nxtB, 2, g + 1, 0); }
+        else G3_ISSUE(curA, curB, 2, g + 1, k_in_tile + 1);
+        {
+            const unsigned a0 = la[0] + sA1, a1 = la[1] + sA1;
+            G3_RD_A(0, a0) G3_RD_A(1, a1)
+            G3_LG1(7, fa[0][0]); G3_MM(1, 1, fb1, 0, 0)
+            G3_LG1(6, fa[1][0]); G3_MM(1, 1, fb1, 1, 0)
+            G3_LG1(5, fa[2][0]); G3_MM(1, 1, fb1, 2, 0)
+            G3_LG1(4, fa[3][0]); G3_MM(1, 1, fb1, 3, 0)
+            G3_LG1(3, fa[0][1]); G3_MM(1, 1, fb1, 0, 1)
+            G3_LG1(2, fa[1][1]); G3_MM(1, 1, fb1, 1, 1)
+            G3_LG1(1, fa[2][1]); G3_MM(1, 1, fb1, 2, 1)
+            G3_LG1(0, fa[3][1]); G3_MM(1, 1, fb1, 3, 1)
+        }
+        // ---- P4 ----
+        G3_MM4(1, 0, fb0, 0) G3_MM4(1, 0, fb0, 1)
+    };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+
+    int g = 0;
+    for (int t = 0; t < ntl; ++t) {
+        k_in_tile = 0;
+        if (t == 0) ktile(g, M1{}); else ktile(g, M0{});
+        ++g;
+        for (k_in_tile = 1; k_in_tile + 1 < nk; ++k_in_tile, ++g) ktile(g, M1{});
+        ktile(g, M2{});
+        ++g;
+        {
+            int tm, tn;
+            walk.decode(it, tm, tn);
+            const float* bl = has_bias ? reinterpret_cast<const float*>(smem + G3_RING + ((it & 1) << 10)) + wn * 64 + (lane >> 4) * 4
+                                       : nullptr;
+            epilogue_p<EPI, 4>(p, acc, (tm << 8) + wm * 128, (tn << 7) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            ++it;
+            curA = nxtA; curB = nxtB;
+            tile_rsrc(it + 1, nxtA, nxtB);
+            if constexpr (!EpiKind<EPI>::dgelu) { if (it < ntl) stage_bias(it); }
+        }
+    }
+#undef G3_ISSUE
+#undef G3_RD
+#undef G3_LG1
+#undef G3_LG2
+#undef G3_LG3
+#undef G3_RD_A
+#undef G3_RD_B
+#undef G3_MM
+#undef G3_MM4
+#undef G3_VM
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1407,6 +1707,32 @@ static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
     return GETMI_OK;
 }
 
+// Width (in N-tiles of `tile_n` columns) of the column groups of TileWalk: the divisor-free choice that minimises the
+// bytes an XCD has to fetch from beyond its L2 under a simple model -- A is fetched once per column group; the B blocks of
+// a group are fetched once per XCD when the group fits in about 2.5 MB of the 4 MiB L2 (they stay resident from round to
+// round), and once per round otherwise.  GETMI_GEMM_GROUP=n forces a width (0 = old round-robin order).
+static int pick_group_n(int M, int N, int K, int tile_m, int tile_n, int grid) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("GETMI_GEMM_GROUP");
+        forced = e ? atoi(e) : -1;
+    }
+    const int tiles_n = (N + tile_n - 1) / tile_n, tiles_m = (M + tile_m - 1) / tile_m;
+    if (forced >= 0) return forced > tiles_n ? tiles_n : forced;
+    if (grid % 8 != 0) return 0;
+    const double a_bytes = 2.0 * M * K, blk = 2.0 * tile_n * K;
+    const double rounds = (double)tiles_m * tiles_n / grid;
+    double best = 0;
+    int best_g = tiles_n;
+    for (int g = 1; g <= tiles_n; ++g) {
+        const int ncg = (tiles_n + g - 1) / g;
+        const bool resident = g * blk <= 2.5e6;
+        const double cost = a_bytes * ncg + (resident ? 8.0 : 8.0 * (rounds < 1 ? 1 : rounds)) * g * blk;
+        if (best == 0 || cost < best - 1.0) { best = cost; best_g = g; }
+    }
+    return best_g;
+}
+
 template <int EPI, int RB1>
 static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
@@ -1418,8 +1744,70 @@ static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
     constexpr int BMv = 128 + 32 * RB1;
     const int ntiles = ((a.M + BMv - 1) / BMv) * ((a.N + 255) / 256);
     const int grid = ntiles < num_cu() ? ntiles : num_cu();
-    hipLaunchKernelGGL((gemm_tn256p_kernel<EPI, RB1>), dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles);
+    static int skew_env = -2;
+    if (skew_env == -2) {
+        const char* e = getenv("GETMI_GEMM_SKEW");
+        skew_env = e ? atoi(e) : -1;
+    }
+    const int skew = skew_env >= 0 ? skew_env : 0;
+    hipLaunchKernelGGL((gemm_tn256p_kernel<EPI, RB1>), dim3(grid), dim3(512), G2_LDS + 1024 + 16384, st, a, ntiles,
+                       pick_group_n(a.M, a.N, a.K, BMv, 256, grid), skew);
     GETMI_CHECK_LAUNCH("gemm_tn256p");
+    return GETMI_OK;
+}
+
+// second generation (gemm_tn2_kernel): which epilogues / shapes take it.  GETMI_GEMM_GEN: 1 = never, 2 = every epilogue it
+// implements, unset = the per-epilogue choice measured on MI355X at the bench shapes.
+static int gemm_gen_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("GETMI_GEMM_GEN");
+        mode = e ? atoi(e) : 0;
+    }
+    return mode;
+}
+template <int EPI>
+static bool use_gen2(const GemmArgs& a) {
+    constexpr bool impl = (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu || EPI == EPI_BIAS_RESID);
+    if (!impl || gemm_gen_mode() == 1) return false;
+    const size_t esz = (EPI == EPI_BIAS_RESID) ? 4 : 2;
+    const bool ok = a.K >= 128 && a.N % 8 == 0 && (size_t)a.M * a.lda * 2 < 0xF0000000ull &&
+                    (size_t)a.N * a.ldb * 2 < 0xF0000000ull && (size_t)a.M * a.ldo * esz < 0xF0000000ull;
+    if (!ok) return false;
+    if (gemm_gen_mode() == 2) return true;
+    // Default: OFF.  Measured on MI355X at M = 51 456 (profiles/r02_gemm_generations.txt): back to back on warm caches the
+    // two-workgroup kernel wins some shapes (qkv forward 207 -> 194 us, proj dgrad 72 -> 66, dGELU-form 334 -> 321) and
+    // loses others (fc1 forward 310 -> 333, plain N = 3072 226 -> 239); INSIDE the training step, where operands come
+    // from HBM / the Infinity Cache rather than from a warm L2, it loses everywhere (plain bf16 GEMMs 145 -> 165 us
+    // average, dGELU-form 308 -> 315; 36.1 -> 36.8 ms per step): its 1.5 x operand traffic per FLOP through the CU's one
+    // vector-memory path costs more than the unsynchronised epilogues give back.  Staggering the two workgroups of a CU
+    // (GETMI_GEMM_STAGGER) or the CUs of the chip (GETMI_GEMM_SKEW) only added their delay.  Kept as GETMI_GEMM_GEN=2.
+    return false;
+}
+
+template <int EPI>
+static int launch_gemm_tn2(const GemmArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel<EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+        attr_set = true;
+    }
+    const int ntiles = ((a.M + 255) / 256) * ((a.N + 127) / 128);
+    const int slots = 2 * num_cu();
+    const int grid = ntiles < slots ? ntiles : slots;
+    // stagger of the second workgroup of each CU, in units of s_sleep 127 (~8 k cycles): half of a tile's main loop at
+    // ~4.5 k cycles per K-tile and workgroup.  GETMI_GEMM_STAGGER overrides (0 = none).
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("GETMI_GEMM_STAGGER");
+        forced = e ? atoi(e) : -1;
+    }
+    const int nk = a.K / 64;
+    const int stagger = forced >= 0 ? forced : (ntiles > slots ? (nk * 9 + 31) / 32 : 0);
+    hipLaunchKernelGGL((gemm_tn2_kernel<EPI>), dim3(grid), dim3(256), G3_LDS, st, a, ntiles,
+                       pick_group_n(a.M, a.N, a.K, 256, 128, grid), stagger);
+    GETMI_CHECK_LAUNCH("gemm_tn2");
     return GETMI_OK;
 }
 
@@ -1487,6 +1875,9 @@ static int launch_gemm_big(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
     if (use_big_tile(a)) {
+        if constexpr (EPI == EPI_BF16 || EpiKind<EPI>::gelu || EpiKind<EPI>::dgelu || EPI == EPI_BIAS_RESID) {
+            if (use_gen2<EPI>(a)) return launch_gemm_tn2<EPI>(a, st);
+        }
         constexpr bool splittable = (EPI == EPI_BF16 || EPI == EPI_BIAS_RESID);
         RowSeg seg[2];
         const int nseg = plan_rows(a.M, a.N, splittable, seg);

@@ -398,3 +398,20 @@ def test_cu_limit_is_read_once_per_call_and_workspaces_stay_valid(K):
         assert len(sizes) == 1
     finally:
         lib.query("getmi_set_cu_limit", 0)
+
+
+def test_second_generation_gemm_kernel_stays_correct():
+    """gemm_tn2_kernel (two workgroups per CU; off by default) is selected per process by
+    GETMI_GEMM_GEN=2: the GEMM tests of this file are re-run under it in a child process (bit-exact integer products,
+    every epilogue, the split-launch shapes), and once more with the pre-round-2 tile order (GETMI_GEMM_GROUP=0)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"GETMI_GEMM_GEN": "2"}, {"GETMI_GEMM_GEN": "1", "GETMI_GEMM_GROUP": "0"}):
+        env = dict(os.environ)
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x",
+                            "-m", "gpu", "-k", "gemm_tn", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-1000:])

@@ -32,6 +32,10 @@ timeit(lambda: K.gemm_tn(K.EPI_BIAS_RESID, xD, wproj, oDf, bias=bD, resid=resid)
 timeit(lambda: K.gemm_tn(K.EPI_BIAS_GELU, xD, w1, oF, out1=oF2, bias=bF), 2.0 * M * F * D, "fc1 fwd  (bias_gelu)")
 timeit(lambda: K.gemm_tn(K.EPI_BIAS_RESID, xF, w2, oDf, bias=bD, resid=resid), 2.0 * M * F * D, "fc2 fwd  (bias_resid)")
 timeit(lambda: K.gemm_tn(K.EPI_DGELU, xD, w1, oF, aux=xF), 2.0 * M * F * D, "fc2 dgrad (dgelu)")
+dbF = torch.empty(F, device=dev)
+timeit(lambda: K.gemm_tn(K.EPI_BIAS_GELUG, xD, w1, oF, out1=oF2, bias=bF), 2.0 * M * F * D, "fc1 fwd  (gelu + gelu', train)")
+timeit(lambda: K.gemm_tn(K.EPI_DMUL, xD, w1, oF, aux=xF, dbias=dbF), 2.0 * M * F * D, "fc2 dgrad (dmul + colsum, train)")
+timeit(lambda: K.gemm_tn(K.EPI_BF16, xD, w1, oF, bias=bF), 2.0 * M * F * D, "N=3072 K=768 plain bf16 +bias")
 timeit(lambda: K.gemm_tn(K.EPI_BF16, xF, w2, oD), 2.0 * M * F * D, "fc1 dgrad (bf16, K=3072)")
 wqkvT = rb(D, 3 * D)
 timeit(lambda: K.gemm_tn(K.EPI_BF16, x3, wqkvT, oD), 2.0 * M * 3 * D * D, "qkv dgrad (bf16, K=2304)")
