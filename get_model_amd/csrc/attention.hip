@@ -16,6 +16,7 @@
 //            over all 256 keys -> no cross-wave or cross-workgroup reduction when T <= 256 (per-key-block fp32
 //            slabs summed by a small kernel otherwise).
 #include "common.h"
+#include <stdlib.h>
 
 #define HD 64
 #define LOG2E 1.4426950408889634f
@@ -273,6 +274,9 @@ struct AttnBwdArgs {
     float* bias_partial;  // [2][B*nkb][H*64] fp32: per-workgroup column sums of dQ (k=0) and dV (k=1), or null
     int B, T, H;
     float scale;
+    int skew;             // diagnostic (GETMI_ATTN_SKEW): first-round workgroups start up to skew x 2048 cycles late.
+                          // Measured: no effect at any spread (profiles/r02_attn_bwd_skew.txt), so the prologue is not an HBM
+                          // burst of synchronised workgroups but the per-CU fetch limit (~10 B/clk from HBM)
 };
 
 // LDS map (bytes).  Everything a workgroup reads is staged ONCE per 256-query chunk (for T <= 256: once), so no
@@ -309,6 +313,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     const float inv_scale = 1.0f / p.scale;
     const int nks = min(8, (T - key_base + 31) >> 5);     // 32-key groups of this workgroup that hold a valid key
     STAMP(0);
+    if (p.skew > 0 && blockIdx.x < 256) {
+        const int n = (int)(((blockIdx.x * 97u) & 255u) * (unsigned)p.skew >> 8);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- K image: 256 rows = 32 wave-instructions, 4 per wave (rows past T clamp to T-1: finite, and their dS is 0) ----
 #pragma unroll
@@ -687,7 +695,12 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_
     const bool want_bias = dq_bias != nullptr || dv_bias != nullptr;
     float* bias_partial = want_bias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + attn_bwd_slab_bytes(B, T, H))
                                     : nullptr;
-    AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale};
+    static int skew_env = -2;
+    if (skew_env == -2) {
+        const char* e = getenv("GETMI_ATTN_SKEW");
+        skew_env = e ? atoi(e) : -1;
+    }
+    AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale, skew_env > 0 ? skew_env : 0};
     const int nkb = (T + 255) / 256;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");
