@@ -624,6 +624,467 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     STAMP(28);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Streamed-prologue backward for T <= 256 (one key block per (b, h)).  Same arithmetic, accumulator layouts and LDS images
+// as attn_bwd_kernel; what changes is WHEN the operands arrive.  attn_bwd_kernel stages everything (K, V, all of Q, dO,
+// and the O / O_lo rows for delta: ~155 KB per workgroup) before its first slice, and at the ~10 B/clk one CU gets
+// while its single resident workgroup waits that prologue is 17-19 k of the kernel's ~47 k cycles.  Here only K, V and
+// the first slice are waited for; the Q / dO / O / O_lo rows of slice X (16 KB = two LDS-DMA instructions per wave)
+// are requested three slices ahead and land while slices X-3 .. X-1 compute:
+//     top of slice s     : request slice s+3 (its O / O_lo ring slot held slice s, whose delta was formed in slice s-1)
+//     during slice s     : delta of slice s+1 from the LDS copies (visible since barrier s-1), 4 queries per wave
+//     end of slice s     : s_waitcnt vmcnt(2) -> this wave's pieces of slice s+2 have landed; barrier s publishes them
+// Every LDS access between the first request and the last barrier is either a plain ds_read / ds_write the compiler
+// does not guard, or inline asm (transposed reads): hipcc would put vmcnt(0) in front of the tr intrinsic.
+#define BS_OSTG (131072 + 2048)   // 3 slots x (O rows 4 KiB | O_lo rows 4 KiB) of one slice
+#define BS_LDS (BS_OSTG + 3 * 8192)
+
+// LDS reads of the streamed kernel in inline asm (see above).  b128 / b64 reads with a compile-time byte offset.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ void bs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (hipcc guards plain LDS WRITES the same way, so the few stores inside the streamed section are asm as well)
+__device__ __forceinline__ void bs_write2_b64(unsigned addr, u32x2_t a, u32x2_t b) {      // addr, addr + 16
+    asm volatile("ds_write2_b64 %0, %1, %2 offset1:2" ::"v"(addr), "v"(a), "v"(b) : "memory");
+}
+__device__ __forceinline__ void bs_write_b32(unsigned addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// dot(4 bf16 of dO, 4 bf16 of O (+ O_lo)) of one lane; reads issued and waited here
+__device__ __forceinline__ float bs_delta_piece(unsigned ado, unsigned ao, bool has_lo) {
+    u32x2_t d, a, e;
+    if (has_lo) {
+        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d), "=&v"(a), "=&v"(e) : "v"(ado), "v"(ao) : "memory");
+    } else {
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(d), "=&v"(a) : "v"(ado), "v"(ao) : "memory");
+        e = (u32x2_t){0u, 0u};
+    }
+    const float a0 = bf2f(a[0] & 0xffff) + bf2f(e[0] & 0xffff), a1 = bf2f(a[0] >> 16) + bf2f(e[0] >> 16);
+    const float a2 = bf2f(a[1] & 0xffff) + bf2f(e[1] & 0xffff), a3 = bf2f(a[1] >> 16) + bf2f(e[1] >> 16);
+    return (a0 * bf2f(d[0] & 0xffff) + a1 * bf2f(d[0] >> 16)) + (a2 * bf2f(d[1] & 0xffff) + a3 * bf2f(d[1] >> 16));
+}
+// sum over the 16 lanes of a DPP row, VALU only (quad xor 1, quad xor 2, row rotate 4, row rotate 8)
+__device__ __forceinline__ float bs_row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true));
+    return v;
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, H = p.H;
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;
+    const int HH = H * HD;
+    const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
+    const bool has_lo = p.out_lo != nullptr;
+    const float* lse = p.lse + ((size_t)b * H + h) * T;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int mykey = wave * 32 + r;
+    const bool wave_active = (wave * 32) < T;
+    const bool wave_ragged = (wave * 32 + 32) > T;
+    const float c2 = p.scale * LOG2E;
+    const float inv_scale = 1.0f / p.scale;
+    const int nks = (T + 31) >> 5;      // 32-key groups with a valid key == 32-query slices
+    const int nsl = nks;
+    float* stf = reinterpret_cast<float*>(smem + BW_ST);
+    const unsigned smem0 = lds_addr(smem);
+    STAMP(0);
+
+    // lse' = -lse / scale (-inf past T -> P = 0): requested first, written to LDS after the first barrier
+
+    // ---- K image (rows past T clamp to T-1) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int I = wave * 4 + j;
+        if (I * 8 < nks * 32) {
+            const int row = I * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ swz128(row);
+            const int key = min(row, T - 1);
+            glds16(base + (size_t)key * rs + HH + chunk * 8, smem + BW_KIMG + I * 1024);
+        }
+    }
+    // V fragments of this wave's 32 keys and the lse row: plain global loads, but in asm -- hipcc waits vmcnt(0) at the
+    // first use of a compiler-visible load while LDS-DMA requests are outstanding, which here would be every slice
+    // request issued below.  Defined after the counted wait that names them.
+    u32x4_t vraw[4];
+    float lraw;
+    {
+        const bf16_t* vp = base + (size_t)min(mykey, T - 1) * rs + 2 * HH + h2 * 8;
+        const float* lp = lse + min(tid, T - 1);
+        asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %5, off offset:64\n\tglobal_load_dwordx4 %3, %5, off offset:96\n\t"
+                     "global_load_dword %4, %6, off"
+                     : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3]), "=&v"(lraw)
+                     : "v"(vp), "v"(lp)
+                     : "memory");
+    }
+    // ---- helpers of the worker wave (wave 7, see below) ----
+    const char* w_base[4] = {reinterpret_cast<const char*>(base),
+                             reinterpret_cast<const char*>(p.dout + (size_t)b * T * HH + h * HD),
+                             reinterpret_cast<const char*>(p.out + (size_t)b * T * HH + h * HD),
+                             reinterpret_cast<const char*>((has_lo ? p.out_lo : p.out) + (size_t)b * T * HH + h * HD)};
+    const int w_row = lane >> 3;                               // row within an 8-row instruction
+    const unsigned w_ch[2] = {(unsigned)(((lane & 7) ^ swz128(w_row)) * 16), (unsigned)(((lane & 7) ^ swz128(w_row + 8)) * 16)};
+    const int n_arr = has_lo ? 4 : 3;
+    auto issue_slice = [&](int X, int slot) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            const unsigned q = (unsigned)min(X * 32 + part * 8 + w_row, T - 1);
+            const unsigned oq = q * (unsigned)(rs * 2) + w_ch[part & 1], oo = q * (unsigned)(HH * 2) + w_ch[part & 1];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a < n_arr) {
+                    char* dst = smem + (a == 0 ? BW_QIMG + X * 4096 : a == 1 ? BW_DOIMG + X * 4096
+                                                                             : BS_OSTG + slot * 8192 + (a - 2) * 4096);
+                    glds16(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
+                }
+            }
+        }
+    };
+    // delta of slice X: lane = (query lane>>1, half lane&1), 32 elements each
+    const int d_lq = lane >> 1;
+    auto delta_slice = [&](int X, int slot) {
+        float acc = 0.f;
+        const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + X * 4096, oo = BS_OSTG + slot * 8192;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned ad = row + ((((lane & 1) * 4 + k) ^ swz128(d_lq)) << 4);
+            u32x4_t d, a, e;
+            if (has_lo)
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(d), "=&v"(a), "=&v"(e) : "v"(ad + od), "v"(ad + oo) : "memory");
+            else {
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(d), "=&v"(a) : "v"(ad + od), "v"(ad + oo) : "memory");
+                e = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                acc += (bf2f(a[w] & 0xffff) + bf2f(e[w] & 0xffff)) * bf2f(d[w] & 0xffff) +
+                       (bf2f(a[w] >> 16) + bf2f(e[w] >> 16)) * bf2f(d[w] >> 16);
+        }
+        acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
+        if ((lane & 1) == 0) bs_write_b32(smem0 + BW_ST + (256 + X * 32 + d_lq) * 4, -acc);   // negated: initial dP'
+    };
+    auto wait_all_but_one_slice = [&]() {      // loads return in order: at most one slice's requests outstanding
+        if (has_lo) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
+    // The worker requests the first three slices right behind its K share; every other wave waits for all it has asked
+    // for (K share, V, lse).  ONE unconditional statement then defines the asm-loaded registers (with a wait in each arm
+    // of an if / else naming them, hipcc merged the two "defined" copies through moves it placed BEFORE one of the
+    // waits: it read registers still in flight).  The worker never uses them.
+    if (wave == 7) {
+        issue_slice(0, 0);
+        if (nsl > 1) issue_slice(1, 1);
+        if (nsl > 2) issue_slice(2, 2);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(63)" : "+v"(vraw[0]), "+v"(vraw[1]), "+v"(vraw[2]), "+v"(vraw[3]), "+v"(lraw)::"memory");
+    STAMP(1);
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+    float dssum = 0.f;
+
+    // K^T fragments of all keys for this wave's dQ d-block (slice-invariant, kept in VGPRs; every wave incl. the worker
+    // computes a dQ tile).  Key rows ks*32 + 8gi + qq (+4): the swizzle of a row depends on (row >> 1) & 7 only, which
+    // ks*32 does not change -> one lane address each for the lower / upper quad, ks * 4096 as the instruction offset.
+    auto load_ktf = [&](bf16x8 (&ktf)[8]) {
+        const int kcol = (wave >> 1) * 16 + 4 * pp;
+        const unsigned kl = smem0 + BW_KIMG + off128(8 * gi + qq, kcol), kh = smem0 + BW_KIMG + off128(8 * gi + qq + 4, kcol);
+        tr64_t t0[8], t1[8];
+        tr_issue8ab<0, 0, 4096, 4096, 8192, 8192, 12288, 12288>(kl, kh, t0);
+        tr_issue8ab<16384, 16384, 20480, 20480, 24576, 24576, 28672, 28672>(kl, kh, t1);
+        tr_wait16(t0, t1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            ktf[ks] = join_tr64(t0[2 * ks], t0[2 * ks + 1]);
+            ktf[4 + ks] = join_tr64(t1[2 * ks], t1[2 * ks + 1]);
+        }
+    };
+    // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys.  dS^T reads: all
+    //      16 of a slice are one lane address + ks * 2048 (+256 for the upper key quad) ----
+    auto dq_tile = [&](const bf16x8 (&ktf)[8], int sl, int dsbuf) {
+        const int qh = wave & 1, dblk = wave >> 1, klo = 8 * gi + qq;
+        const unsigned dsa = smem0 + BW_DS + dsbuf * 16384 +
+                             (unsigned)(klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | ((4 * pp) << 1)));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        tr64_t ta[8], tb[8];
+        tr_issue8ab<0, 256, 2048, 2048 + 256, 4096, 4096 + 256, 6144, 6144 + 256>(dsa, dsa, ta);
+        tr_issue8ab<8192, 8192 + 256, 10240, 10240 + 256, 12288, 12288 + 256, 14336, 14336 + 256>(dsa, dsa, tb);
+        tr_wait16(ta, tb);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            if (ks < nks) acc = MFMA16(ktf[ks], join_tr64(ta[2 * ks], ta[2 * ks + 1]), acc);
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks)
+            if (ks < nks) acc = MFMA16(ktf[ks], join_tr64(tb[2 * (ks - 4)], tb[2 * (ks - 4) + 1]), acc);
+        const int q = sl * 32 + qh * 16 + (lane & 15);
+        const int d0 = dblk * 16 + (lane >> 4) * 4;
+        if (q < T)
+            *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
+                pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+    };
+
+    if (wave == 7) {
+        // ======== worker wave.  T <= 224 (host-checked) leaves wave 7 without keys; it requests every slice (Q, dO, O, O_lo
+        // rows: 16 LDS-DMA instructions of 8 rows each, 12 without O_lo) and forms delta, so that the seven key-owning waves
+        // run nothing but the slice arithmetic.  (Spread over all waves, the requests and delta cost each of them ~800
+        // cycles per slice -- profiles/r02_attn_bwd_stream_stamps.txt -- which ate the prologue's gain.)  It is a code
+        // path of its own so that its addresses and the key-owners' accumulators never share the register file.
+        STAMP(2);
+        if (nsl > 2) {          // slice 0 landed: slices 1, 2 may be outstanding
+            if (has_lo) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        bs_barrier();           // P1: K image and slice 0 visible
+        STAMP(3);
+        bf16x8 ktf[8];
+        load_ktf(ktf);
+        delta_slice(0, 0);
+        if (nsl > 2) wait_all_but_one_slice();      // slice 1 landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bs_barrier();           // P2: lse', delta(0), slice 1 visible
+        STAMP(4);
+        int dsbuf = 0, slot_next = 0;      // ring slot of slice sl + 3 (== slot of slice sl); slice sl + 1 is slot_next + 1
+        for (int sl = 0; sl < nsl; ++sl) {
+            if (sl + 3 < nsl) issue_slice(sl + 3, slot_next);
+            if (sl + 1 < nsl) delta_slice(sl + 1, slot_next == 2 ? 0 : slot_next + 1);
+            if (sl < 7) STAMP(5 + 3 * sl);
+            // slice sl+2 has landed when only slice sl+3's requests may be outstanding (this wave's dQ stores can only
+            // lower the count)
+            if (sl + 3 < nsl) wait_all_but_one_slice();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bs_barrier();
+            if (sl < 7) STAMP(6 + 3 * sl);
+            dq_tile(ktf, sl, dsbuf);
+            if (sl < 7) STAMP(7 + 3 * sl);
+            dsbuf ^= 1;
+            slot_next = slot_next == 2 ? 0 : slot_next + 1;
+        }
+    } else {
+        // ======== key-owning waves (and idle ones when T <= 192: they only take part in the barriers and dQ tiles) ========
+        STAMP(2);
+        bf16x8 vf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vf[kk] = __builtin_bit_cast(bf16x8, vraw[kk]);
+        bs_barrier();           // P1
+        STAMP(3);
+        bf16x8 ktf[8];
+        load_ktf(ktf);
+        if (tid < 256) bs_write_b32(smem0 + BW_ST + tid * 4, tid < T ? -lraw * inv_scale : -INFINITY);
+        bs_barrier();           // P2
+        // lane addresses of the in-loop reads.  Transposed Q / dO: rows qlo (lo) and qlo + 8 (hi) of d block db; the second
+        // 16-query half is +2048 bytes and the dO image +32768 bytes from the Q image, both as instruction offsets.  Row
+        // fragments of K / Q / dO: one address per 16-element K step (the chunk swizzle is lane dependent).
+        unsigned tq[2][2], fk[4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int qlo = 4 * h2 + qq, col = db * 32 + 16 * (gi & 1) + 4 * pp;
+            tq[db][0] = smem0 + BW_QIMG + (unsigned)off128(qlo, col);
+            tq[db][1] = smem0 + BW_QIMG + (unsigned)off128(qlo + 8, col);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)      // this lane's K row piece; the Q piece of slice sl is (32768 + (sl - wave) * 4096) above it
+            fk[kk] = smem0 + BW_KIMG + (wave * 32 + r) * 128 + (((2 * kk + h2) ^ swz128(r)) << 4);
+        const unsigned st_a = smem0 + BW_ST + h2 * 16;
+        const unsigned ds_wa = smem0 + BW_DS + (wave * 32 + r) * 64 + ((((wave * 32 + r) >> 3) & 1) << 5) + 8 * h2;
+        const unsigned ds_wb = smem0 + BW_DS + (wave * 32 + r) * 64 + (((((wave * 32 + r) >> 3) & 1) ^ 1) << 5) + 8 * h2;
+        STAMP(4);
+        int dsbuf = 0;
+        for (int sl = 0; sl < nsl; ++sl) {
+            if (wave_active) {
+                // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2.  Initial values (lse', delta) and the
+                // row fragments of K / Q / dO: 20 reads in issue order, consumed under counted lgkmcnt waits
+                u32x4_t ia[4], id[4], fa[4], fd[4], fkr[4];
+                {
+                    const unsigned sa = st_a + sl * 128, so = 32768 + (sl - wave) * 4096;
+                    asm volatile(
+                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
+                        "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:1024\n\tds_read_b128 %5, %8 offset:1056\n\t"
+                        "ds_read_b128 %6, %8 offset:1088\n\tds_read_b128 %7, %8 offset:1120"
+                        : "=&v"(ia[0]), "=&v"(ia[1]), "=&v"(ia[2]), "=&v"(ia[3]), "=&v"(id[0]), "=&v"(id[1]), "=&v"(id[2]), "=&v"(id[3])
+                        : "v"(sa)
+                        : "memory");
+                    asm volatile(
+                        "ds_read_b128 %0, %12\n\tds_read_b128 %1, %16\n\tds_read_b128 %2, %16 offset:32768\n\t"
+                        "ds_read_b128 %3, %13\n\tds_read_b128 %4, %17\n\tds_read_b128 %5, %17 offset:32768\n\t"
+                        "ds_read_b128 %6, %14\n\tds_read_b128 %7, %18\n\tds_read_b128 %8, %18 offset:32768\n\t"
+                        "ds_read_b128 %9, %15\n\tds_read_b128 %10, %19\n\tds_read_b128 %11, %19 offset:32768"
+                        : "=&v"(fkr[0]), "=&v"(fa[0]), "=&v"(fd[0]), "=&v"(fkr[1]), "=&v"(fa[1]), "=&v"(fd[1]),
+                          "=&v"(fkr[2]), "=&v"(fa[2]), "=&v"(fd[2]), "=&v"(fkr[3]), "=&v"(fa[3]), "=&v"(fd[3])
+                        : "v"(fk[0]), "v"(fk[1]), "v"(fk[2]), "v"(fk[3]), "v"(fk[0] + so), "v"(fk[1] + so), "v"(fk[2] + so), "v"(fk[3] + so)
+                        : "memory");
+                }
+                f32x16 s, dp;
+                asm volatile("s_waitcnt lgkmcnt(9)"
+                             : "+v"(ia[0]), "+v"(ia[1]), "+v"(ia[2]), "+v"(ia[3]), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]),
+                               "+v"(fa[0]), "+v"(fd[0]), "+v"(fkr[0]) :: "memory");
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[4 * g4 + e] = __uint_as_float(ia[g4][e]);
+                        dp[4 * g4 + e] = __uint_as_float(id[g4][e]);
+                    }
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[0]), __builtin_bit_cast(bf16x8, fkr[0]), s);   // S' = Q.K^T - lse/scale
+                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[0]), vf[0], dp);                               // dP' = dO.V^T - delta
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[1]), "+v"(fd[1]), "+v"(fkr[1]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[1]), __builtin_bit_cast(bf16x8, fkr[1]), s);
+                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[1]), vf[1], dp);
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[2]), "+v"(fd[2]), "+v"(fkr[2]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[2]), __builtin_bit_cast(bf16x8, fkr[2]), s);
+                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[2]), vf[2], dp);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[3]), "+v"(fd[3]), "+v"(fkr[3]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[3]), __builtin_bit_cast(bf16x8, fkr[3]), s);
+                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[3]), vf[3], dp);
+                // transposed Q / dO fragments for dK / dV: requested here, consumed after the softmax arithmetic
+                tr64_t ta[8], tb[8];
+                {
+                    const unsigned so = sl * 4096;
+                    // per d block, order: dO lo, dO hi, Q lo, Q hi of query half 0, then the same of half 1 (+2048)
+                    tr_issue8ab<32768, 32768, 0, 0, 32768 + 2048, 32768 + 2048, 2048, 2048>(tq[0][0] + so, tq[0][1] + so, ta);
+                    tr_issue8ab<32768, 32768, 0, 0, 32768 + 2048, 32768 + 2048, 2048, 2048>(tq[1][0] + so, tq[1][1] + so, tb);
+                }
+                // (VALU-lean: the softmax scale of dS is applied once to the dK / dQ results, not per element)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s[i] = __builtin_amdgcn_exp2f(s[i] * c2);   // P
+                    dp[i] = s[i] * dp[i];                       // dS / scale
+                }
+                if (wave_ragged) {
+                    const bool kvalid = mykey < T;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        s[i] = kvalid ? s[i] : 0.f;
+                        dp[i] = kvalid ? dp[i] : 0.f;
+                    }
+                }
+                dssum += (((dp[0] + dp[1]) + (dp[2] + dp[3])) + ((dp[4] + dp[5]) + (dp[6] + dp[7]))) +
+                         (((dp[8] + dp[9]) + (dp[10] + dp[11])) + ((dp[12] + dp[13]) + (dp[14] + dp[15])));
+                bf16x8 pf[2], dsf[2];
+                pf[0] = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+                pf[1] = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+                dsf[0] = pack8(dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[7]);
+                dsf[1] = pack8(dp[8], dp[9], dp[10], dp[11], dp[12], dp[13], dp[14], dp[15]);
+                {
+                    // dS^T image: row = key, 32 q per row (64 B); 32-B halves swapped when (key>>3)&1; this lane's 4 pieces
+                    // of 4 queries sit at A, A + 16 (queries 4h2.., 8 + 4h2..) and B, B + 16 (16 + 4h2.., 24 + 4h2..)
+                    const u32x2_t* d2 = reinterpret_cast<const u32x2_t*>(dsf);
+                    const unsigned o = dsbuf * 16384;
+                    bs_write2_b64(ds_wa + o, d2[0], d2[1]);
+                    bs_write2_b64(ds_wb + o, d2[2], d2[3]);
+                }
+                tr_wait16(ta, tb);
+                // dV^T[d][key] += dO^T[d][q].P[q][key] ; dK^T[d][key] += Q^T[d][q].dS[q][key]
+                dv[0] = MFMA32(join_tr64(ta[0], ta[1]), pf[0], dv[0]);
+                dk[0] = MFMA32(join_tr64(ta[2], ta[3]), dsf[0], dk[0]);
+                dv[0] = MFMA32(join_tr64(ta[4], ta[5]), pf[1], dv[0]);
+                dk[0] = MFMA32(join_tr64(ta[6], ta[7]), dsf[1], dk[0]);
+                dv[1] = MFMA32(join_tr64(tb[0], tb[1]), pf[0], dv[1]);
+                dk[1] = MFMA32(join_tr64(tb[2], tb[3]), dsf[0], dk[1]);
+                dv[1] = MFMA32(join_tr64(tb[4], tb[5]), pf[1], dv[1]);
+                dk[1] = MFMA32(join_tr64(tb[6], tb[7]), dsf[1], dk[1]);
+            }
+            if (sl < 7) STAMP(5 + 3 * sl);
+            bs_barrier();
+            if (sl < 7) STAMP(6 + 3 * sl);
+            dq_tile(ktf, sl, dsbuf);
+            if (sl < 7) STAMP(7 + 3 * sl);
+            dsbuf ^= 1;
+        }
+    }
+
+    STAMP(26);
+    if (p.bias_partial != nullptr) {
+        // as in attn_bwd_kernel (no LDS-DMA is in flight any more: plain LDS accesses)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem + BW_DS);
+        {
+            float v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k] = dv[k >> 4][k & 15];
+#pragma unroll
+            for (int m = 16, n = 32; m > 0; m >>= 1, n >>= 1) {
+                const bool up = (lane & m) != 0;
+#pragma unroll
+                for (int j = 0; j < n / 2; ++j) {
+                    const float lo = v[j], hi = v[j + n / 2];
+                    v[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, 64);
+                }
+            }
+            const int i = r & 15;
+            red[wave * 64 + (r >> 4) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = v[0];
+        }
+        {
+            const float cs = dssum + __shfl_xor(dssum, 32, 64);
+            float part = 0.f;
+            if (wave_active) {
+#pragma unroll
+                for (int rr = 0; rr < 32; ++rr) {
+                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), rr));
+                    const int krow = wave * 32 + rr;
+                    const bf16_t kv = *reinterpret_cast<const bf16_t*>(
+                        smem + BW_KIMG + krow * 128 + ((((lane >> 3) ^ swz128(krow)) << 4) | ((lane & 7) << 1)));
+                    part = fmaf(c, bf2f(kv), part);
+                }
+            }
+            red[512 + wave * 64 + lane] = part;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int d = tid & 63;
+            float v = 0.f;
+            if (tid < 64) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[512 + w * 64 + d];
+                v *= p.scale;
+            } else {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
+            }
+            p.bias_partial[((size_t)(tid >> 6) * p.B + b) * HH + h * HD + d] = v;
+        }
+    }
+    STAMP(27);
+    if (wave_active) {
+        char* blk = smem + BW_KIMG + wave * 8192;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + 8 * g4 + 4 * h2;
+                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale,
+                                                    dk[db][4 * g4 + 2] * p.scale, dk[db][4 * g4 + 3] * p.scale));
+                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2],
+                                                         dv[db][4 * g4 + 3]));
+            }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = stage_row_chunk(blk, row, ch);
+            const int key = wave * 32 + (row & 31);
+            if (key < T)
+                *reinterpret_cast<uint4*>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8) = v;
+        }
+    }
+    STAMP(28);
+}
+
 // dqkv[b,t,0,h,:] = bf16(sum over key blocks of dq_acc[kb][b,t,h,:])   (long-context path only)
 __global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __restrict__ dqkv, size_t ntok,
                                        int H, int nkb) {
@@ -702,7 +1163,18 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_
     }
     AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale, skew_env > 0 ? skew_env : 0};
     const int nkb = (T + 255) / 256;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
+    // T <= 224: the streamed-prologue kernel (GETMI_ATTN_STREAM=0 keeps the staged one)
+    static int stream_env = -1;
+    if (stream_env < 0) {
+        const char* e = getenv("GETMI_ATTN_STREAM");
+        stream_env = e ? atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
+    }
+    if (T <= 224 && stream_env != 0)      // wave 7 must be free of keys: it is the kernel's staging worker
+        hipLaunchKernelGGL(attn_bwd_stream_kernel, dim3(B * H), dim3(512), BS_LDS, st, a);
+    else
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");
     if (dq_acc) {
         const size_t n4 = (size_t)B * T * H * (HD / 4);

@@ -131,6 +131,18 @@ __device__ __forceinline__ void tr_issue8o(const unsigned (&a)[8], tr64_t (&r)[8
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(OFF)
         : "memory");
 }
+// eight reads from TWO lane addresses (even reads from a, odd reads from b) with a compile-time byte offset each
+template <int O0, int O1, int O2, int O3, int O4, int O5, int O6, int O7>
+__device__ __forceinline__ void tr_issue8ab(unsigned a, unsigned b, tr64_t (&r)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%14\n\tds_read_b64_tr_b16 %5, %9 offset:%15\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:%16\n\tds_read_b64_tr_b16 %7, %9 offset:%17"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+        : "v"(a), "v"(b), "n"(O0), "n"(O1), "n"(O2), "n"(O3), "n"(O4), "n"(O5), "n"(O6), "n"(O7)
+        : "memory");
+}
 __device__ __forceinline__ void tr_wait8(tr64_t (&a)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])

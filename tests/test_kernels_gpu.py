@@ -242,6 +242,35 @@ def test_attention_fwd_bwd(K, B, T, H):
         assert err <= tol, f"attn.{name} err {err:.3e} > {tol:.3e}"
 
 
+@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (2, 70, 1), (1, 97, 2), (2, 256, 2), (1, 300, 1)])
+def test_attention_bwd_with_output_residual(K, B, T, H):
+    """out_lo path (delta from O + its rounding residual): dqkv as without it to rounding, and the q_bias sums -- a pure
+    cancellation sum -- an order of magnitude closer to the fp32 reference than the 4e-3 bar of the plain path."""
+    scale = 0.125
+    qkv = bf(rnd(B * T, 3 * H * 64, scale=1.5, seed=29))
+    out, lse, lo = K.attention_fwd(qkv, B, T, H, scale, want_lo=True)
+    out_p, lse_p = K.attention_fwd(qkv, B, T, H, scale)
+    assert torch.equal(out, out_p) and torch.equal(lse, lse_p)
+    qr = qkv.float().requires_grad_(True)
+    ref, _ = attn_ref(qr, B, T, H, scale)
+    # lo is the rounding residual of the kernel's own fp32 output (which carries the bf16 rounding of P): within half an
+    # ulp of `out`, and out + lo no further from the reference than out
+    assert (lo.float().abs() <= out.float().abs() * 2.0 ** -8 + 1e-30).all()
+    close(out.float() + lo.float(), ref, 8e-3, 4e-3, "attn.out+lo")
+    dout = bf(rnd(B * T, H * 64, seed=30))
+    ref.backward(dout.float())
+    g = qr.grad
+    dqkv, dqb, dvb = K.attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=True, out_lo=lo)
+    err = (dqkv.float() - g).abs().max().item()
+    assert err <= 1.5e-2 * g.abs().max().item(), f"attn.dqkv(lo) err {err:.3e}"
+    assert F.cosine_similarity(dqkv.float().flatten(), g.flatten(), dim=0).item() > 0.9995
+    D = H * 64
+    for name, got, third, rel in (("dq_bias", dqb, g[:, :D], 1e-3), ("dv_bias", dvb, g[:, 2 * D:], 4e-3)):
+        tol = rel * third.abs().sum(0).max().item()
+        err = (got - third.sum(0)).abs().max().item()
+        assert err <= tol, f"attn.{name}(lo) err {err:.3e} > {tol:.3e}"
+
+
 def test_attention_online_softmax_rescale(K):
     # a late key with a huge score forces the running-max rescale branch in a late chunk
     B, T, H = 1, 201, 1

@@ -27,9 +27,13 @@ if __name__ == "__main__":
     g = torch.Generator(device="cpu").manual_seed(0)
     x = (torch.randn(B * T, 3 * H * 64, generator=g) * 0.5).bfloat16().cuda()
     do = (torch.randn(B * T, H * 64, generator=g) * 0.5).bfloat16().cuda()
-    o, lse = K.attention_fwd(x, B, T, H, 0.125)
+    step_like = len(sys.argv) > 1 and sys.argv[1] == "lo"       # as the training step calls it: O_lo + fused bias sums
+    if step_like:
+        o, lse, olo = K.attention_fwd(x, B, T, H, 0.125, want_lo=True)
+    else:
+        (o, lse), olo = K.attention_fwd(x, B, T, H, 0.125), None
     for _ in range(5):
-        K.attention_bwd(x, o, do, lse, B, T, H, 0.125)
+        K.attention_bwd(x, o, do, lse, B, T, H, 0.125, want_bias=step_like, out_lo=olo)
     torch.cuda.synchronize()
     lib = ctypes.CDLL(out)
     n = B * H * 8 * 32
@@ -38,7 +42,7 @@ if __name__ == "__main__":
     assert rc == 0, rc
     st = buf.reshape(B * H, 8, 32).astype(np.int64)
     names = ["entry->setup", "setup->staged-issue", "issue->landed(barrier)", "barrier->K frags"]
-    for w in (0, 3, 6, 7):
+    for w in range(8):
         s = st[256:2816, w, :]                     # steady-state workgroups
         d = np.diff(s[:, :5], axis=1)
         line = [f"{names[i]} {int(np.median(d[:, i]))}" for i in range(4)]

@@ -22,4 +22,8 @@ for B, T in ((256, 201), (16, 2001), (64, 129)):
     f = timeit(lambda: K.attention_fwd(x, B, T, H, 0.125))
     b = timeit(lambda: K.attention_bwd(x, out, do, lse, B, T, H, 0.125))
     fl = 4.0 * B * H * T * T * 64
+    if T == 201:      # as the training step calls it: residual of the output + fused bias sums
+        out2, lse2, lo = K.attention_fwd(x, B, T, H, 0.125, want_lo=True)
+        b2 = timeit(lambda: K.attention_bwd(x, out2, do, lse2, B, T, H, 0.125, want_bias=True, out_lo=lo))
+        print(f"B={B} T={T} (out_lo + bias sums): bwd {b2:8.1f} us {2.5 * fl / b2 / 1e6:7.1f} TF", flush=True)
     print(f"B={B} T={T}: fwd {f:8.1f} us {fl / f / 1e6:7.1f} TF   bwd {b:8.1f} us {2.5 * fl / b / 1e6:7.1f} TF", flush=True)
