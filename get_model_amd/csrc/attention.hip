@@ -260,6 +260,36 @@ extern "C" int getmi_debug_attn_stamps(void* dst, size_t bytes) {
 #define STAMP(i) do {} while (0)
 #endif
 
+// One level of a reduce-scatter butterfly over lane bit M (M = 32, 16, 8, 4, 2, 1): lanes with the bit clear end with
+// lo + lo(partner), lanes with it set with hi + hi(partner); partner = lane ^ M.  v_permlane16_swap exchanges the odd
+// 16-lane rows of its first operand with the even rows of its second, which is exactly the M = 16 exchange; below that the
+// partner is a DPP row rotation / quad permutation.  (ds_bpermute shuffles made this reduction 2 k cycles per workgroup.)
+template <int M>
+__device__ __forceinline__ float bfly_level(float lo, float hi, bool up) {
+    if constexpr (M == 32) {         // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+        typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+        const u2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (M == 16) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u2_t;
+        const u2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+        // lanes with the bit clear read lane + M, lanes with it set read lane - M (row_ror:n reads lane - n mod 16)
+        constexpr int CLR = M == 8 ? 0x128 : M == 4 ? 0x12C : M == 2 ? 0x4E : 0xB1;
+        constexpr int SET = M == 8 ? 0x128 : M == 4 ? 0x124 : M == 2 ? 0x4E : 0xB1;
+        const float a = lo + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(lo), CLR, 0xf, 0xf, true));
+        const float b = hi + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(hi), SET, 0xf, 0xf, true));
+        return up ? b : a;
+    }
+}
+template <int M>
+__device__ __forceinline__ void bfly_reduce(float (&v)[32], int lane) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = bfly_level<M>(v[j], v[j + M], up);
+}
+
 struct AttnBwdArgs {
     const bf16_t* qkv;
     const bf16_t* out;    // [B,T,H*64] forward output (for delta = rowsum(dO * O))
@@ -543,20 +573,17 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
         __syncthreads();                                   // every wave is done with the dS images: reuse them
         float* red = reinterpret_cast<float*>(smem + BW_DS);          // [8 waves][64] dV | [8 waves][64] dQ at +512
         {
-            // butterfly reduce-scatter over the 32 lanes of a half wave: 16+8+4+2+1 exchanges instead of 32 x 5;
+            // butterfly reduce-scatter over the 32 lanes of a half wave: 16+8+4+2+1 exchanges instead of 32 x 5, each a
+            // lane-row swap or DPP add (bfly_level);
             // lane r ends with the sum over keys of accumulator register r (= db*16 + i)
             float v[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) v[k] = dv[k >> 4][k & 15];
-#pragma unroll
-            for (int m = 16, n = 32; m > 0; m >>= 1, n >>= 1) {
-                const bool up = (lane & m) != 0;
-#pragma unroll
-                for (int j = 0; j < n / 2; ++j) {
-                    const float lo = v[j], hi = v[j + n / 2];
-                    v[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, 64);
-                }
-            }
+            bfly_reduce<16>(v, lane);
+            bfly_reduce<8>(v, lane);
+            bfly_reduce<4>(v, lane);
+            bfly_reduce<2>(v, lane);
+            bfly_reduce<1>(v, lane);
             const int i = r & 15;
             red[wave * 64 + (r >> 4) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = v[0];
         }
@@ -564,19 +591,32 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             // dQ: partial[d] = sum over this wave's 32 keys of (sum_q dS[q][key]) * K[key][d], d = lane.  The K image is
             // still whole (the dK / dV staging below overwrites it only after the next barrier); rows of waves past T
             // were never staged, hence the wave_active guard (their column sums are 0 anyway).
-            const float cs = dssum + __shfl_xor(dssum, 32, 64);      // both query halves of key r
-            float part = 0.f;
+            // lane = (key quad kg = lane>>3, 8-column chunk ch = lane&7): four 16-byte K pieces times the column sums of
+            // their keys, then a reduce-scatter over the eight key quads (lane bits 5, 4, 3) leaves one column per lane.
+            // (One key per iteration with a 2-byte LDS read each was 1.5 k cycles per workgroup.)
+            const float cs = dssum + __shfl_xor(dssum, 32, 64);      // both query halves of key r, in every lane r, r + 32
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (wave_active) {
+                const int kg = lane >> 3, ch = lane & 7;
 #pragma unroll
-                for (int rr = 0; rr < 32; ++rr) {
-                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), rr));
-                    const int krow = wave * 32 + rr;
-                    const bf16_t kv = *reinterpret_cast<const bf16_t*>(
-                        smem + BW_KIMG + krow * 128 + ((((lane >> 3) ^ swz128(krow)) << 4) | ((lane & 7) << 1)));
-                    part = fmaf(c, bf2f(kv), part);
+                for (int i = 0; i < 4; ++i) {
+                    const float c = __shfl(cs, kg * 4 + i, 64);
+                    const int krow = wave * 32 + kg * 4 + i;
+                    const uint4 kv = *reinterpret_cast<const uint4*>(smem + BW_KIMG + krow * 128 + ((ch ^ swz128(krow)) << 4));
+                    const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        a8[2 * w] = fmaf(c, bf2f(kw[w] & 0xffff), a8[2 * w]);
+                        a8[2 * w + 1] = fmaf(c, bf2f(kw[w] >> 16), a8[2 * w + 1]);
+                    }
                 }
             }
-            red[512 + wave * 64 + lane] = part;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a8[j] = bfly_level<32>(a8[j], a8[j + 4], (lane & 32) != 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a8[j] = bfly_level<16>(a8[j], a8[j + 2], (lane & 16) != 0);
+            a8[0] = bfly_level<8>(a8[0], a8[1], (lane & 8) != 0);
+            red[512 + wave * 64 + (lane & 7) * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)] = a8[0];
         }
         __syncthreads();
         if (tid < 128) {
@@ -753,25 +793,39 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     // delta of slice X: lane = (query lane>>1, half lane&1), 32 elements each
     const int d_lq = lane >> 1;
     auto delta_slice = [&](int X, int slot) {
-        float acc = 0.f;
         const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + X * 4096, oo = BS_OSTG + slot * 8192;
+        unsigned ad[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned ad = row + ((((lane & 1) * 4 + k) ^ swz128(d_lq)) << 4);
-            u32x4_t d, a, e;
-            if (has_lo)
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(d), "=&v"(a), "=&v"(e) : "v"(ad + od), "v"(ad + oo) : "memory");
-            else {
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(d), "=&v"(a) : "v"(ad + od), "v"(ad + oo) : "memory");
-                e = (u32x4_t){0u, 0u, 0u, 0u};
-            }
+        for (int k = 0; k < 4; ++k) ad[k] = row + ((((lane & 1) * 4 + k) ^ swz128(d_lq)) << 4);
+        u32x4_t d[4], a[4], e[4];
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                     "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+                     : "v"(ad[0] + od), "v"(ad[1] + od), "v"(ad[2] + od), "v"(ad[3] + od),
+                       "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
+                     : "memory");
+        // (the O_lo pieces are read unconditionally -- stale LDS without O_lo -- and dropped after the wait: defining them in
+        //  two arms of an if would let hipcc merge the arms with moves in front of the wait, see the note at the V fragments)
+        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\t"
+                     "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096"
+                     : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                     : "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
+                     : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                       "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])
+                     :: "memory");
+        if (!has_lo) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = (u32x4_t){0u, 0u, 0u, 0u};
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int w = 0; w < 4; ++w)
-                acc += (bf2f(a[w] & 0xffff) + bf2f(e[w] & 0xffff)) * bf2f(d[w] & 0xffff) +
-                       (bf2f(a[w] >> 16) + bf2f(e[w] >> 16)) * bf2f(d[w] >> 16);
-        }
+                acc += (bf2f(a[k][w] & 0xffff) + bf2f(e[k][w] & 0xffff)) * bf2f(d[k][w] & 0xffff) +
+                       (bf2f(a[k][w] >> 16) + bf2f(e[k][w] >> 16)) * bf2f(d[k][w] >> 16);
         acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
         if ((lane & 1) == 0) bs_write_b32(smem0 + BW_ST + (256 + X * 32 + d_lq) * 4, -acc);   // negated: initial dP'
     };
@@ -851,11 +905,11 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        delta_slice(0, 0);      // from the worker's own requests: no barrier needed, and it runs while the others wait for K / V
         bs_barrier();           // P1: K image and slice 0 visible
         STAMP(3);
         bf16x8 ktf[8];
         load_ktf(ktf);
-        delta_slice(0, 0);
         if (nsl > 2) wait_all_but_one_slice();      // slice 1 landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bs_barrier();           // P2: lse', delta(0), slice 1 visible
@@ -901,6 +955,17 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)      // this lane's K row piece; the Q piece of slice sl is (32768 + (sl - wave) * 4096) above it
             fk[kk] = smem0 + BW_KIMG + (wave * 32 + r) * 128 + (((2 * kk + h2) ^ swz128(r)) << 4);
+        bf16x8 kfr[4];      // this wave's K rows as the B operand of S = Q.K^T (slice-invariant)
+        {
+            u32x4_t k0, k1, k2, k3;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3) : "v"(fk[0]), "v"(fk[1]), "v"(fk[2]), "v"(fk[3]) : "memory");
+            kfr[0] = __builtin_bit_cast(bf16x8, k0); kfr[1] = __builtin_bit_cast(bf16x8, k1);
+            kfr[2] = __builtin_bit_cast(bf16x8, k2); kfr[3] = __builtin_bit_cast(bf16x8, k3);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fk[kk] += 32768 - wave * 4096;      // now the Q piece of slice 0
         const unsigned st_a = smem0 + BW_ST + h2 * 16;
         const unsigned ds_wa = smem0 + BW_DS + (wave * 32 + r) * 64 + ((((wave * 32 + r) >> 3) & 1) << 5) + 8 * h2;
         const unsigned ds_wb = smem0 + BW_DS + (wave * 32 + r) * 64 + (((((wave * 32 + r) >> 3) & 1) ^ 1) << 5) + 8 * h2;
@@ -909,10 +974,10 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         for (int sl = 0; sl < nsl; ++sl) {
             if (wave_active) {
                 // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2.  Initial values (lse', delta) and the
-                // row fragments of K / Q / dO: 20 reads in issue order, consumed under counted lgkmcnt waits
-                u32x4_t ia[4], id[4], fa[4], fd[4], fkr[4];
+                // row fragments of Q / dO: 16 reads in issue order, consumed under counted lgkmcnt waits
+                u32x4_t ia[4], id[4], fa[4], fd[4];
                 {
-                    const unsigned sa = st_a + sl * 128, so = 32768 + (sl - wave) * 4096;
+                    const unsigned sa = st_a + sl * 128, so = sl * 4096;
                     asm volatile(
                         "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
                         "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:1024\n\tds_read_b128 %5, %8 offset:1056\n\t"
@@ -921,19 +986,17 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                         : "v"(sa)
                         : "memory");
                     asm volatile(
-                        "ds_read_b128 %0, %12\n\tds_read_b128 %1, %16\n\tds_read_b128 %2, %16 offset:32768\n\t"
-                        "ds_read_b128 %3, %13\n\tds_read_b128 %4, %17\n\tds_read_b128 %5, %17 offset:32768\n\t"
-                        "ds_read_b128 %6, %14\n\tds_read_b128 %7, %18\n\tds_read_b128 %8, %18 offset:32768\n\t"
-                        "ds_read_b128 %9, %15\n\tds_read_b128 %10, %19\n\tds_read_b128 %11, %19 offset:32768"
-                        : "=&v"(fkr[0]), "=&v"(fa[0]), "=&v"(fd[0]), "=&v"(fkr[1]), "=&v"(fa[1]), "=&v"(fd[1]),
-                          "=&v"(fkr[2]), "=&v"(fa[2]), "=&v"(fd[2]), "=&v"(fkr[3]), "=&v"(fa[3]), "=&v"(fd[3])
-                        : "v"(fk[0]), "v"(fk[1]), "v"(fk[2]), "v"(fk[3]), "v"(fk[0] + so), "v"(fk[1] + so), "v"(fk[2] + so), "v"(fk[3] + so)
+                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32768\n\tds_read_b128 %2, %9\n\t"
+                        "ds_read_b128 %3, %9 offset:32768\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:32768\n\t"
+                        "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:32768"
+                        : "=&v"(fa[0]), "=&v"(fd[0]), "=&v"(fa[1]), "=&v"(fd[1]), "=&v"(fa[2]), "=&v"(fd[2]), "=&v"(fa[3]), "=&v"(fd[3])
+                        : "v"(fk[0] + so), "v"(fk[1] + so), "v"(fk[2] + so), "v"(fk[3] + so)
                         : "memory");
                 }
                 f32x16 s, dp;
-                asm volatile("s_waitcnt lgkmcnt(9)"
+                asm volatile("s_waitcnt lgkmcnt(6)"
                              : "+v"(ia[0]), "+v"(ia[1]), "+v"(ia[2]), "+v"(ia[3]), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]),
-                               "+v"(fa[0]), "+v"(fd[0]), "+v"(fkr[0]) :: "memory");
+                               "+v"(fa[0]), "+v"(fd[0]) :: "memory");
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
@@ -941,16 +1004,16 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                         s[4 * g4 + e] = __uint_as_float(ia[g4][e]);
                         dp[4 * g4 + e] = __uint_as_float(id[g4][e]);
                     }
-                s = MFMA32(__builtin_bit_cast(bf16x8, fa[0]), __builtin_bit_cast(bf16x8, fkr[0]), s);   // S' = Q.K^T - lse/scale
-                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[0]), vf[0], dp);                               // dP' = dO.V^T - delta
-                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[1]), "+v"(fd[1]), "+v"(fkr[1]) :: "memory");
-                s = MFMA32(__builtin_bit_cast(bf16x8, fa[1]), __builtin_bit_cast(bf16x8, fkr[1]), s);
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[0]), kfr[0], s);      // S' = Q.K^T - lse/scale
+                dp = MFMA32(__builtin_bit_cast(bf16x8, fd[0]), vf[0], dp);     // dP' = dO.V^T - delta
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[1]), "+v"(fd[1]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[1]), kfr[1], s);
                 dp = MFMA32(__builtin_bit_cast(bf16x8, fd[1]), vf[1], dp);
-                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[2]), "+v"(fd[2]), "+v"(fkr[2]) :: "memory");
-                s = MFMA32(__builtin_bit_cast(bf16x8, fa[2]), __builtin_bit_cast(bf16x8, fkr[2]), s);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[2]), "+v"(fd[2]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[2]), kfr[2], s);
                 dp = MFMA32(__builtin_bit_cast(bf16x8, fd[2]), vf[2], dp);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[3]), "+v"(fd[3]), "+v"(fkr[3]) :: "memory");
-                s = MFMA32(__builtin_bit_cast(bf16x8, fa[3]), __builtin_bit_cast(bf16x8, fkr[3]), s);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[3]), "+v"(fd[3]) :: "memory");
+                s = MFMA32(__builtin_bit_cast(bf16x8, fa[3]), kfr[3], s);
                 dp = MFMA32(__builtin_bit_cast(bf16x8, fd[3]), vf[3], dp);
                 // transposed Q / dO fragments for dK / dV: requested here, consumed after the softmax arithmetic
                 tr64_t ta[8], tb[8];
@@ -1018,32 +1081,41 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             float v[32];
 #pragma unroll
             for (int k = 0; k < 32; ++k) v[k] = dv[k >> 4][k & 15];
-#pragma unroll
-            for (int m = 16, n = 32; m > 0; m >>= 1, n >>= 1) {
-                const bool up = (lane & m) != 0;
-#pragma unroll
-                for (int j = 0; j < n / 2; ++j) {
-                    const float lo = v[j], hi = v[j + n / 2];
-                    v[j] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, 64);
-                }
-            }
+            bfly_reduce<16>(v, lane);
+            bfly_reduce<8>(v, lane);
+            bfly_reduce<4>(v, lane);
+            bfly_reduce<2>(v, lane);
+            bfly_reduce<1>(v, lane);
             const int i = r & 15;
             red[wave * 64 + (r >> 4) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2] = v[0];
         }
         {
-            const float cs = dssum + __shfl_xor(dssum, 32, 64);
-            float part = 0.f;
+            // lane = (key quad kg = lane>>3, 8-column chunk ch = lane&7): four 16-byte K pieces times the column sums of
+            // their keys, then a reduce-scatter over the eight key quads (lane bits 5, 4, 3) leaves one column per lane.
+            // (One key per iteration with a 2-byte LDS read each was 1.5 k cycles per workgroup.)
+            const float cs = dssum + __shfl_xor(dssum, 32, 64);      // both query halves of key r, in every lane r, r + 32
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (wave_active) {
+                const int kg = lane >> 3, ch = lane & 7;
 #pragma unroll
-                for (int rr = 0; rr < 32; ++rr) {
-                    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), rr));
-                    const int krow = wave * 32 + rr;
-                    const bf16_t kv = *reinterpret_cast<const bf16_t*>(
-                        smem + BW_KIMG + krow * 128 + ((((lane >> 3) ^ swz128(krow)) << 4) | ((lane & 7) << 1)));
-                    part = fmaf(c, bf2f(kv), part);
+                for (int i = 0; i < 4; ++i) {
+                    const float c = __shfl(cs, kg * 4 + i, 64);
+                    const int krow = wave * 32 + kg * 4 + i;
+                    const uint4 kv = *reinterpret_cast<const uint4*>(smem + BW_KIMG + krow * 128 + ((ch ^ swz128(krow)) << 4));
+                    const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        a8[2 * w] = fmaf(c, bf2f(kw[w] & 0xffff), a8[2 * w]);
+                        a8[2 * w + 1] = fmaf(c, bf2f(kw[w] >> 16), a8[2 * w + 1]);
+                    }
                 }
             }
-            red[512 + wave * 64 + lane] = part;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a8[j] = bfly_level<32>(a8[j], a8[j + 4], (lane & 32) != 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a8[j] = bfly_level<16>(a8[j], a8[j + 2], (lane & 16) != 0);
+            a8[0] = bfly_level<8>(a8[0], a8[1], (lane & 8) != 0);
+            red[512 + wave * 64 + (lane & 7) * 8 + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)] = a8[0];
         }
         __syncthreads();
         if (tid < 128) {
