@@ -676,7 +676,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
 //     end of slice s     : s_waitcnt vmcnt(2) -> this wave's pieces of slice s+2 have landed; barrier s publishes them
 // Every LDS access between the first request and the last barrier is either a plain ds_read / ds_write the compiler
 // does not guard, or inline asm (transposed reads): hipcc would put vmcnt(0) in front of the tr intrinsic.
-#define BS_OSTG (131072 + 2048)   // 3 slots x (O rows 4 KiB | O_lo rows 4 KiB) of one slice
+#define BS_STAT 131072            // [256 q][16 B]: -lse/scale and -delta of query q as three bf16 terms each (see bs_split3)
+#define BS_OSTG (131072 + 4096)   // 3 slots x (O rows 4 KiB | O_lo rows 4 KiB) of one slice
 #define BS_LDS (BS_OSTG + 3 * 8192)
 
 // LDS reads of the streamed kernel in inline asm (see above).  b128 / b64 reads with a compile-time byte offset.
@@ -687,8 +688,19 @@ __device__ __forceinline__ void bs_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void bs_write2_b64(unsigned addr, u32x2_t a, u32x2_t b) {      // addr, addr + 16
     asm volatile("ds_write2_b64 %0, %1, %2 offset1:2" ::"v"(addr), "v"(a), "v"(b) : "memory");
 }
-__device__ __forceinline__ void bs_write_b32(unsigned addr, float v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+__device__ __forceinline__ void bs_write_b64(unsigned addr, u32x2_t v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// x as the sum of three bf16 numbers (truncations, so every remainder is exact: 24 mantissa bits in all), packed as the
+// first three elements of an MFMA operand row.  The per-query constants -lse/scale and -delta enter the S' and dP'
+// accumulators through ONE extra MFMA each against a row of ones, instead of eight 16-byte LDS reads per wave and slice
+// that initialised the accumulators (a third of the kernel's ds_read_b128 traffic; the LDS pipe is its busiest unit).
+__device__ __forceinline__ u32x2_t bs_split3(float x) {
+    const unsigned h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    const unsigned l = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(l);
+    return (u32x2_t){(h >> 16) | l, __float_as_uint(r2) >> 16};
 }
 // dot(4 bf16 of dO, 4 bf16 of O (+ O_lo)) of one lane; reads issued and waited here
 __device__ __forceinline__ float bs_delta_piece(unsigned ado, unsigned ao, bool has_lo) {
@@ -752,110 +764,16 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             glds16(base + (size_t)key * rs + HH + chunk * 8, smem + BW_KIMG + I * 1024);
         }
     }
-    // V fragments of this wave's 32 keys and the lse row: plain global loads, but in asm -- hipcc waits vmcnt(0) at the
-    // first use of a compiler-visible load while LDS-DMA requests are outstanding, which here would be every slice
-    // request issued below.  Defined after the counted wait that names them.
-    u32x4_t vraw[4];
-    float lraw;
-    {
-        const bf16_t* vp = base + (size_t)min(mykey, T - 1) * rs + 2 * HH + h2 * 8;
-        const float* lp = lse + min(tid, T - 1);
-        asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:32\n\t"
-                     "global_load_dwordx4 %2, %5, off offset:64\n\tglobal_load_dwordx4 %3, %5, off offset:96\n\t"
-                     "global_load_dword %4, %6, off"
-                     : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3]), "=&v"(lraw)
-                     : "v"(vp), "v"(lp)
-                     : "memory");
-    }
-    // ---- helpers of the worker wave (wave 7, see below) ----
-    const char* w_base[4] = {reinterpret_cast<const char*>(base),
-                             reinterpret_cast<const char*>(p.dout + (size_t)b * T * HH + h * HD),
-                             reinterpret_cast<const char*>(p.out + (size_t)b * T * HH + h * HD),
-                             reinterpret_cast<const char*>((has_lo ? p.out_lo : p.out) + (size_t)b * T * HH + h * HD)};
-    const int w_row = lane >> 3;                               // row within an 8-row instruction
-    const unsigned w_ch[2] = {(unsigned)(((lane & 7) ^ swz128(w_row)) * 16), (unsigned)(((lane & 7) ^ swz128(w_row + 8)) * 16)};
-    const int n_arr = has_lo ? 4 : 3;
-    auto issue_slice = [&](int X, int slot) {
-#pragma unroll
-        for (int part = 0; part < 4; ++part) {
-            const unsigned q = (unsigned)min(X * 32 + part * 8 + w_row, T - 1);
-            const unsigned oq = q * (unsigned)(rs * 2) + w_ch[part & 1], oo = q * (unsigned)(HH * 2) + w_ch[part & 1];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (a < n_arr) {
-                    char* dst = smem + (a == 0 ? BW_QIMG + X * 4096 : a == 1 ? BW_DOIMG + X * 4096
-                                                                             : BS_OSTG + slot * 8192 + (a - 2) * 4096);
-                    glds16(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
-                }
-            }
-        }
-    };
-    // delta of slice X: lane = (query lane>>1, half lane&1), 32 elements each
-    const int d_lq = lane >> 1;
-    auto delta_slice = [&](int X, int slot) {
-        const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + X * 4096, oo = BS_OSTG + slot * 8192;
-        unsigned ad[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ad[k] = row + ((((lane & 1) * 4 + k) ^ swz128(d_lq)) << 4);
-        u32x4_t d[4], a[4], e[4];
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
-                     "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
-                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
-                     : "v"(ad[0] + od), "v"(ad[1] + od), "v"(ad[2] + od), "v"(ad[3] + od),
-                       "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
-                     : "memory");
-        // (the O_lo pieces are read unconditionally -- stale LDS without O_lo -- and dropped after the wait: defining them in
-        //  two arms of an if would let hipcc merge the arms with moves in front of the wait, see the note at the V fragments)
-        asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\t"
-                     "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096"
-                     : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
-                     : "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
-                     : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
-                       "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])
-                     :: "memory");
-        if (!has_lo) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) e[k] = (u32x4_t){0u, 0u, 0u, 0u};
-        }
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                acc += (bf2f(a[k][w] & 0xffff) + bf2f(e[k][w] & 0xffff)) * bf2f(d[k][w] & 0xffff) +
-                       (bf2f(a[k][w] >> 16) + bf2f(e[k][w] >> 16)) * bf2f(d[k][w] >> 16);
-        acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
-        if ((lane & 1) == 0) bs_write_b32(smem0 + BW_ST + (256 + X * 32 + d_lq) * 4, -acc);   // negated: initial dP'
-    };
-    auto wait_all_but_one_slice = [&]() {      // loads return in order: at most one slice's requests outstanding
-        if (has_lo) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    };
-    // The worker requests the first three slices right behind its K share; every other wave waits for all it has asked
-    // for (K share, V, lse).  ONE unconditional statement then defines the asm-loaded registers (with a wait in each arm
-    // of an if / else naming them, hipcc merged the two "defined" copies through moves it placed BEFORE one of the
-    // waits: it read registers still in flight).  The worker never uses them.
-    if (wave == 7) {
-        issue_slice(0, 0);
-        if (nsl > 1) issue_slice(1, 1);
-        if (nsl > 2) issue_slice(2, 2);
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(63)" : "+v"(vraw[0]), "+v"(vraw[1]), "+v"(vraw[2]), "+v"(vraw[3]), "+v"(lraw)::"memory");
     STAMP(1);
 
-    f32x16 dk[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
-    float dssum = 0.f;
+    f32x16 dk[2], dv[2];     // zeroed at the START of the key-owners' path and at the END of the worker's (which has none)
+    float dssum;
 
     // K^T fragments of all keys for this wave's dQ d-block (slice-invariant, kept in VGPRs; every wave incl. the worker
     // computes a dQ tile).  Key rows ks*32 + 8gi + qq (+4): the swizzle of a row depends on (row >> 1) & 7 only, which
     // ks*32 does not change -> one lane address each for the lower / upper quad, ks * 4096 as the instruction offset.
-    auto load_ktf = [&](bf16x8 (&ktf)[8]) {
+    auto load_ktf = [&](bf16x8 (&ktf)[8], int ln) {      // ln: the caller's copy of the lane id (see the worker path)
+        const int gi = ln >> 4, qq = (ln >> 2) & 3, pp = ln & 3;
         const int kcol = (wave >> 1) * 16 + 4 * pp;
         const unsigned kl = smem0 + BW_KIMG + off128(8 * gi + qq, kcol), kh = smem0 + BW_KIMG + off128(8 * gi + qq + 4, kcol);
         tr64_t t0[8], t1[8];
@@ -870,7 +788,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     };
     // ---- dQ^T tile [16 d][16 q] per wave: d-block = wave>>1, q-half = wave&1; sum over all valid keys.  dS^T reads: all
     //      16 of a slice are one lane address + ks * 2048 (+256 for the upper key quad) ----
-    auto dq_tile = [&](const bf16x8 (&ktf)[8], int sl, int dsbuf) {
+    auto dq_tile = [&](const bf16x8 (&ktf)[8], int sl, int dsbuf, int ln) {
+        const int gi = ln >> 4, qq = (ln >> 2) & 3, pp = ln & 3;
         const int qh = wave & 1, dblk = wave >> 1, klo = 8 * gi + qq;
         const unsigned dsa = smem0 + BW_DS + dsbuf * 16384 +
                              (unsigned)(klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | ((4 * pp) << 1)));
@@ -885,8 +804,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int ks = 4; ks < 8; ++ks)
             if (ks < nks) acc = MFMA16(ktf[ks], join_tr64(tb[2 * (ks - 4)], tb[2 * (ks - 4) + 1]), acc);
-        const int q = sl * 32 + qh * 16 + (lane & 15);
-        const int d0 = dblk * 16 + (lane >> 4) * 4;
+        const int q = sl * 32 + qh * 16 + (ln & 15);
+        const int d0 = dblk * 16 + (ln >> 4) * 4;
         if (q < T)
             *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
                 pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
@@ -898,6 +817,79 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         // run nothing but the slice arithmetic.  (Spread over all waves, the requests and delta cost each of them ~800
         // cycles per slice -- profiles/r02_attn_bwd_stream_stamps.txt -- which ate the prologue's gain.)  It is a code
         // path of its own so that its addresses and the key-owners' accumulators never share the register file.
+        // An opaque copy of the lane id: everything lane-derived in this path is recomputed from it, so that no value of the
+        // common code (which hipcc had spilled around the key-owners' loop) is reloaded here -- a scratch reload while
+        // LDS-DMA is in flight costs a vmcnt(0).
+        int wl;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(wl) : "v"(lane));
+        const char* w_base[4] = {reinterpret_cast<const char*>(base),
+                                 reinterpret_cast<const char*>(p.dout + (size_t)b * T * HH + h * HD),
+                                 reinterpret_cast<const char*>(p.out + (size_t)b * T * HH + h * HD),
+                                 reinterpret_cast<const char*>((has_lo ? p.out_lo : p.out) + (size_t)b * T * HH + h * HD)};
+        const int w_row = wl >> 3;                               // row within an 8-row instruction
+        const unsigned w_ch[2] = {(unsigned)(((wl & 7) ^ swz128(w_row)) * 16), (unsigned)(((wl & 7) ^ swz128(w_row + 8)) * 16)};
+        const int n_arr = has_lo ? 4 : 3;
+        auto issue_slice = [&](int X, int slot) {
+    #pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const unsigned q = (unsigned)min(X * 32 + part * 8 + w_row, T - 1);
+                const unsigned oq = q * (unsigned)(rs * 2) + w_ch[part & 1], oo = q * (unsigned)(HH * 2) + w_ch[part & 1];
+    #pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (a < n_arr) {
+                        char* dst = smem + (a == 0 ? BW_QIMG + X * 4096 : a == 1 ? BW_DOIMG + X * 4096
+                                                                                 : BS_OSTG + slot * 8192 + (a - 2) * 4096);
+                        glds16(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
+                    }
+                }
+            }
+        };
+        // delta of slice X: wl = (query wl>>1, half wl&1), 32 elements each
+        const int d_lq = wl >> 1;
+        auto delta_slice = [&](int X, int slot) {
+            const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + X * 4096, oo = BS_OSTG + slot * 8192;
+            unsigned ad[4];
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) ad[k] = row + ((((wl & 1) * 4 + k) ^ swz128(d_lq)) << 4);
+            u32x4_t d[4], a[4], e[4];
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                         "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                         : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+                         : "v"(ad[0] + od), "v"(ad[1] + od), "v"(ad[2] + od), "v"(ad[3] + od),
+                           "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
+                         : "memory");
+            // (the O_lo pieces are read unconditionally -- stale LDS without O_lo -- and dropped after the wait: defining them in
+            //  two arms of an if would let hipcc merge the arms with moves in front of the wait, see the note at the V fragments)
+            asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\t"
+                         "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096"
+                         : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+                         : "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
+                         : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                           "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])
+                         :: "memory");
+            if (!has_lo) {
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = (u32x4_t){0u, 0u, 0u, 0u};
+            }
+            float acc = 0.f;
+    #pragma unroll
+            for (int k = 0; k < 4; ++k)
+    #pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    acc += (bf2f(a[k][w] & 0xffff) + bf2f(e[k][w] & 0xffff)) * bf2f(d[k][w] & 0xffff) +
+                           (bf2f(a[k][w] >> 16) + bf2f(e[k][w] >> 16)) * bf2f(d[k][w] >> 16);
+            acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
+            if ((wl & 1) == 0) bs_write_b64(smem0 + BS_STAT + (X * 32 + d_lq) * 16 + 8, bs_split3(-acc));   // negated: enters dP'
+        };
+        auto wait_all_but_one_slice = [&]() {      // loads return in order: at most one slice's requests outstanding
+            if (has_lo) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        };
+        issue_slice(0, 0);      // right behind this wave's K share
+        if (nsl > 1) issue_slice(1, 1);
+        if (nsl > 2) issue_slice(2, 2);
         STAMP(2);
         if (nsl > 2) {          // slice 0 landed: slices 1, 2 may be outstanding
             if (has_lo) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -909,7 +901,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         bs_barrier();           // P1: K image and slice 0 visible
         STAMP(3);
         bf16x8 ktf[8];
-        load_ktf(ktf);
+        load_ktf(ktf, wl);
         if (nsl > 2) wait_all_but_one_slice();      // slice 1 landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bs_barrier();           // P2: lse', delta(0), slice 1 visible
@@ -925,22 +917,46 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bs_barrier();
             if (sl < 7) STAMP(6 + 3 * sl);
-            dq_tile(ktf, sl, dsbuf);
+            dq_tile(ktf, sl, dsbuf, wl);
             if (sl < 7) STAMP(7 + 3 * sl);
             dsbuf ^= 1;
             slot_next = slot_next == 2 ? 0 : slot_next + 1;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+        dssum = 0.f;
     } else {
         // ======== key-owning waves (and idle ones when T <= 192: they only take part in the barriers and dQ tiles) ========
+        // V fragments of this wave's 32 keys and the lse row: plain global loads, but in asm together with their wait --
+        // hipcc waits vmcnt(0) at the first use of a compiler-visible load while LDS-DMA requests are outstanding, and a
+        // register with an asm load in flight must not be visible to it as free (an earlier version issued these loads in
+        // the common code: the worker never named the registers, hipcc reused them for its address arithmetic, the landing
+        // loads overwrote those, and the kernel faulted).  The wait also covers this wave's K share.
+        u32x4_t vraw[4];
+        float lraw;
+        {
+            const bf16_t* vp = base + (size_t)min(mykey, T - 1) * rs + 2 * HH + h2 * 8;
+            const float* lp = lse + min(tid, T - 1);
+            asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %5, off offset:64\n\tglobal_load_dwordx4 %3, %5, off offset:96\n\t"
+                         "global_load_dword %4, %6, off\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3]), "=&v"(lraw)
+                         : "v"(vp), "v"(lp)
+                         : "memory");
+        }
         STAMP(2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+        dssum = 0.f;
         bf16x8 vf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) vf[kk] = __builtin_bit_cast(bf16x8, vraw[kk]);
         bs_barrier();           // P1
         STAMP(3);
         bf16x8 ktf[8];
-        load_ktf(ktf);
-        if (tid < 256) bs_write_b32(smem0 + BW_ST + tid * 4, tid < T ? -lraw * inv_scale : -INFINITY);
+        load_ktf(ktf, lane);
+        // (rows past T: a finite stand-in for -inf, so that the split stays finite and P underflows to exactly 0)
+        if (tid < 256) bs_write_b64(smem0 + BS_STAT + tid * 16, bs_split3(tid < T ? -lraw * inv_scale : -60000.f));
         bs_barrier();           // P2
         // lane addresses of the in-loop reads.  Transposed Q / dO: rows qlo (lo) and qlo + 8 (hi) of d block db; the second
         // 16-query half is +2048 bytes and the dO image +32768 bytes from the Q image, both as instruction offsets.  Row
@@ -966,44 +982,41 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fk[kk] += 32768 - wave * 4096;      // now the Q piece of slice 0
-        const unsigned st_a = smem0 + BW_ST + h2 * 16;
+        const unsigned st_a = smem0 + BS_STAT + r * 16;
+        const unsigned hmask = h2 ? 0u : 0xffffffffu;      // the constants ride on k = 0..2 of the extra K step: lanes of half 0
         const unsigned ds_wa = smem0 + BW_DS + (wave * 32 + r) * 64 + ((((wave * 32 + r) >> 3) & 1) << 5) + 8 * h2;
         const unsigned ds_wb = smem0 + BW_DS + (wave * 32 + r) * 64 + (((((wave * 32 + r) >> 3) & 1) ^ 1) << 5) + 8 * h2;
         STAMP(4);
         int dsbuf = 0;
         for (int sl = 0; sl < nsl; ++sl) {
             if (wave_active) {
-                // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2.  Initial values (lse', delta) and the
-                // row fragments of Q / dO: 16 reads in issue order, consumed under counted lgkmcnt waits
-                u32x4_t ia[4], id[4], fa[4], fd[4];
+                // accumulator rows are queries: q(reg) = (reg&3) + 8*(reg>>2) + 4*h2.  This lane's query constants and the
+                // row fragments of Q / dO: 9 reads in issue order, consumed under counted lgkmcnt waits
+                u32x4_t stq, fa[4], fd[4];
                 {
-                    const unsigned sa = st_a + sl * 128, so = sl * 4096;
+                    const unsigned sa = st_a + sl * 512, so = sl * 4096;
                     asm volatile(
-                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
-                        "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:1024\n\tds_read_b128 %5, %8 offset:1056\n\t"
-                        "ds_read_b128 %6, %8 offset:1088\n\tds_read_b128 %7, %8 offset:1120"
-                        : "=&v"(ia[0]), "=&v"(ia[1]), "=&v"(ia[2]), "=&v"(ia[3]), "=&v"(id[0]), "=&v"(id[1]), "=&v"(id[2]), "=&v"(id[3])
-                        : "v"(sa)
-                        : "memory");
-                    asm volatile(
-                        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32768\n\tds_read_b128 %2, %9\n\t"
-                        "ds_read_b128 %3, %9 offset:32768\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %10 offset:32768\n\t"
-                        "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:32768"
-                        : "=&v"(fa[0]), "=&v"(fd[0]), "=&v"(fa[1]), "=&v"(fd[1]), "=&v"(fa[2]), "=&v"(fd[2]), "=&v"(fa[3]), "=&v"(fd[3])
-                        : "v"(fk[0] + so), "v"(fk[1] + so), "v"(fk[2] + so), "v"(fk[3] + so)
+                        "ds_read_b128 %0, %9\n\t"
+                        "ds_read_b128 %1, %10\n\tds_read_b128 %2, %10 offset:32768\n\tds_read_b128 %3, %11\n\t"
+                        "ds_read_b128 %4, %11 offset:32768\n\tds_read_b128 %5, %12\n\tds_read_b128 %6, %12 offset:32768\n\t"
+                        "ds_read_b128 %7, %13\n\tds_read_b128 %8, %13 offset:32768"
+                        : "=&v"(stq), "=&v"(fa[0]), "=&v"(fd[0]), "=&v"(fa[1]), "=&v"(fd[1]), "=&v"(fa[2]), "=&v"(fd[2]), "=&v"(fa[3]),
+                          "=&v"(fd[3])
+                        : "v"(sa), "v"(fk[0] + so), "v"(fk[1] + so), "v"(fk[2] + so), "v"(fk[3] + so)
                         : "memory");
                 }
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(stq) :: "memory");
                 f32x16 s, dp;
-                asm volatile("s_waitcnt lgkmcnt(6)"
-                             : "+v"(ia[0]), "+v"(ia[1]), "+v"(ia[2]), "+v"(ia[3]), "+v"(id[0]), "+v"(id[1]), "+v"(id[2]), "+v"(id[3]),
-                               "+v"(fa[0]), "+v"(fd[0]) :: "memory");
+                {
+                    const u32x4_t al = {stq[0] & hmask, stq[1] & hmask, 0u, 0u}, ad = {stq[2] & hmask, stq[3] & hmask, 0u, 0u};
+                    const u32x4_t ones = {0x3F803F80u & hmask, 0x00003F80u & hmask, 0u, 0u};
+                    f32x16 zero;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s[4 * g4 + e] = __uint_as_float(ia[g4][e]);
-                        dp[4 * g4 + e] = __uint_as_float(id[g4][e]);
-                    }
+                    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+                    s = MFMA32(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, ones), zero);    // -lse/scale
+                    dp = MFMA32(__builtin_bit_cast(bf16x8, ad), __builtin_bit_cast(bf16x8, ones), zero);   // -delta
+                }
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fa[0]), "+v"(fd[0]) :: "memory");
                 s = MFMA32(__builtin_bit_cast(bf16x8, fa[0]), kfr[0], s);      // S' = Q.K^T - lse/scale
                 dp = MFMA32(__builtin_bit_cast(bf16x8, fd[0]), vf[0], dp);     // dP' = dO.V^T - delta
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[1]), "+v"(fd[1]) :: "memory");
@@ -1066,7 +1079,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             if (sl < 7) STAMP(5 + 3 * sl);
             bs_barrier();
             if (sl < 7) STAMP(6 + 3 * sl);
-            dq_tile(ktf, sl, dsbuf);
+            dq_tile(ktf, sl, dsbuf, lane);
             if (sl < 7) STAMP(7 + 3 * sl);
             dsbuf ^= 1;
         }
