@@ -678,7 +678,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
 // does not guard, or inline asm (transposed reads): hipcc would put vmcnt(0) in front of the tr intrinsic.
 #define BS_STAT 131072            // [256 q][16 B]: -lse/scale and -delta of query q as three bf16 terms each (see bs_split3)
 #define BS_OSTG (131072 + 4096)   // 3 slots x (O rows 4 KiB | O_lo rows 4 KiB) of one slice
-#define BS_LDS (BS_OSTG + 3 * 8192)
+#define BS_LSE (BS_OSTG + 3 * 8192)   // 8 slots x 64 fp32: the lse rows of a slice (+ the next 32, unused), by dword LDS-DMA
+#define BS_LDS (BS_LSE + 2048)
 
 // LDS reads of the streamed kernel in inline asm (see above).  b128 / b64 reads with a compile-time byte offset.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -690,6 +691,9 @@ __device__ __forceinline__ void bs_write2_b64(unsigned addr, u32x2_t a, u32x2_t 
 }
 __device__ __forceinline__ void bs_write_b64(unsigned addr, u32x2_t v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void bs_write_b128(unsigned addr, u32x4_t v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 // x as the sum of three bf16 numbers (truncations, so every remainder is exact: 24 mantissa bits in all), packed as the
 // first three elements of an MFMA operand row.  The per-query constants -lse/scale and -delta enter the S' and dP'
@@ -731,8 +735,11 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, H = p.H;
-    const int bh = blockIdx.x;
+    // key blocks of 224 keys (seven key-owning waves + the worker) when T > 224; every block sweeps all query slices
+    const int nkb = T <= 224 ? 1 : (T + 223) / 224;
+    const int bh = blockIdx.x / nkb, kbi = blockIdx.x - bh * nkb;
     const int b = bh / H, h = bh - b * H;
+    const int key_base = kbi * 224;
     const size_t rs = (size_t)3 * H * HD;
     const int HH = H * HD;
     const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
@@ -740,18 +747,17 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     const float* lse = p.lse + ((size_t)b * H + h) * T;
     const int r = lane & 31, h2 = lane >> 5;
     const int gi = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int mykey = wave * 32 + r;
-    const bool wave_active = (wave * 32) < T;
-    const bool wave_ragged = (wave * 32 + 32) > T;
+    const int mykey = key_base + wave * 32 + r;
+    const bool wave_active = wave < 7 && (key_base + wave * 32) < T;       // wave 7 is the worker: it never owns keys
+    const bool wave_ragged = (key_base + wave * 32 + 32) > T;
     const float c2 = p.scale * LOG2E;
     const float inv_scale = 1.0f / p.scale;
-    const int nks = (T + 31) >> 5;      // 32-key groups with a valid key == 32-query slices
-    const int nsl = nks;
-    float* stf = reinterpret_cast<float*>(smem + BW_ST);
+    const int nks = min(7, (T - key_base + 31) >> 5);      // 32-key groups of this block with a valid key
+    const int nsl = (T + 31) >> 5;                           // 32-query slices
+    // Q / dO images and the constants table are rings of 8 slices (slot = slice & 7; for T <= 224 every slice has its own
+    // slot), the O / O_lo stage a ring of 3: slice X is requested during slice X-3 and last read during slice X.
     const unsigned smem0 = lds_addr(smem);
     STAMP(0);
-
-    // lse' = -lse / scale (-inf past T -> P = 0): requested first, written to LDS after the first barrier
 
     // ---- K image (rows past T clamp to T-1) ----
 #pragma unroll
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         if (I * 8 < nks * 32) {
             const int row = I * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ swz128(row);
-            const int key = min(row, T - 1);
+            const int key = min(key_base + row, T - 1);
             glds16(base + (size_t)key * rs + HH + chunk * 8, smem + BW_KIMG + I * 1024);
         }
     }
@@ -806,14 +812,19 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             if (ks < nks) acc = MFMA16(ktf[ks], join_tr64(tb[2 * (ks - 4)], tb[2 * (ks - 4) + 1]), acc);
         const int q = sl * 32 + qh * 16 + (ln & 15);
         const int d0 = dblk * 16 + (ln >> 4) * 4;
-        if (q < T)
-            *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
-                pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+        if (q < T) {
+            if (p.dq_acc == nullptr)
+                *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
+                    pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+            else      // several key blocks: this block's partial dQ goes to its own fp32 slab, summed by attn_dq_convert
+                *reinterpret_cast<float4*>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0) =
+                    make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+        }
     };
 
     if (wave == 7) {
-        // ======== worker wave.  T <= 224 (host-checked) leaves wave 7 without keys; it requests every slice (Q, dO, O, O_lo
-        // rows: 16 LDS-DMA instructions of 8 rows each, 12 without O_lo) and forms delta, so that the seven key-owning waves
+        // ======== worker wave.  Wave 7 never owns keys (T <= 224, or key blocks of 224); it requests every slice (Q, dO, O, O_lo
+        // rows: 16 LDS-DMA instructions of 8 rows each, 12 without O_lo, + 1 for the lse rows) and forms delta, so that the seven key-owning waves
         // run nothing but the slice arithmetic.  (Spread over all waves, the requests and delta cost each of them ~800
         // cycles per slice -- profiles/r02_attn_bwd_stream_stamps.txt -- which ate the prologue's gain.)  It is a code
         // path of its own so that its addresses and the key-owners' accumulators never share the register file.
@@ -837,17 +848,19 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (a < n_arr) {
-                        char* dst = smem + (a == 0 ? BW_QIMG + X * 4096 : a == 1 ? BW_DOIMG + X * 4096
-                                                                                 : BS_OSTG + slot * 8192 + (a - 2) * 4096);
+                        char* dst = smem + (a == 0 ? BW_QIMG + (X & 7) * 4096 : a == 1 ? BW_DOIMG + (X & 7) * 4096
+                                                                                       : BS_OSTG + slot * 8192 + (a - 2) * 4096);
                         glds16(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
                     }
                 }
             }
+            // + the lse rows of the slice, one dword per lane (lanes 32-63 fetch the next slice's: unused)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(lse + min(X * 32 + wl, T - 1)), LDS_PTR(smem + BS_LSE + (X & 7) * 256), 4, 0, 0);
         };
-        // delta of slice X: wl = (query wl>>1, half wl&1), 32 elements each
+        // constants of slice X: -lse/scale and -delta.  delta: wl = (query wl>>1, half wl&1), 32 elements each
         const int d_lq = wl >> 1;
         auto delta_slice = [&](int X, int slot) {
-            const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + X * 4096, oo = BS_OSTG + slot * 8192;
+            const unsigned row = smem0 + d_lq * 128, od = BW_DOIMG + (X & 7) * 4096, oo = BS_OSTG + slot * 8192;
             unsigned ad[4];
     #pragma unroll
             for (int k = 0; k < 4; ++k) ad[k] = row + ((((wl & 1) * 4 + k) ^ swz128(d_lq)) << 4);
@@ -860,14 +873,16 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                          : "memory");
             // (the O_lo pieces are read unconditionally -- stale LDS without O_lo -- and dropped after the wait: defining them in
             //  two arms of an if would let hipcc merge the arms with moves in front of the wait, see the note at the V fragments)
-            asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %5 offset:4096\n\t"
-                         "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %7 offset:4096"
-                         : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
-                         : "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo)
+            float lv;
+            asm volatile("ds_read_b128 %0, %5 offset:4096\n\tds_read_b128 %1, %6 offset:4096\n\t"
+                         "ds_read_b128 %2, %7 offset:4096\n\tds_read_b128 %3, %8 offset:4096\n\tds_read_b32 %4, %9"
+                         : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(lv)
+                         : "v"(ad[0] + oo), "v"(ad[1] + oo), "v"(ad[2] + oo), "v"(ad[3] + oo),
+                           "v"(smem0 + BS_LSE + (X & 7) * 256 + d_lq * 4)
                          : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
-                           "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3])
+                           "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(lv)
                          :: "memory");
             if (!has_lo) {
     #pragma unroll
@@ -881,19 +896,23 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                     acc += (bf2f(a[k][w] & 0xffff) + bf2f(e[k][w] & 0xffff)) * bf2f(d[k][w] & 0xffff) +
                            (bf2f(a[k][w] >> 16) + bf2f(e[k][w] >> 16)) * bf2f(d[k][w] >> 16);
             acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
-            if ((wl & 1) == 0) bs_write_b64(smem0 + BS_STAT + (X * 32 + d_lq) * 16 + 8, bs_split3(-acc));   // negated: enters dP'
+            if ((wl & 1) == 0) {      // negated: they enter S' and dP'.  Rows past T: a finite stand-in for -inf, so that the
+                                      // split stays finite and P underflows to exactly 0
+                const u32x2_t cl = bs_split3(X * 32 + d_lq < T ? -lv * inv_scale : -60000.f), cd = bs_split3(-acc);
+                bs_write_b128(smem0 + BS_STAT + ((X & 7) * 32 + d_lq) * 16, (u32x4_t){cl[0], cl[1], cd[0], cd[1]});
+            }
         };
         auto wait_all_but_one_slice = [&]() {      // loads return in order: at most one slice's requests outstanding
-            if (has_lo) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (has_lo) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
         };
         issue_slice(0, 0);      // right behind this wave's K share
         if (nsl > 1) issue_slice(1, 1);
         if (nsl > 2) issue_slice(2, 2);
         STAMP(2);
         if (nsl > 2) {          // slice 0 landed: slices 1, 2 may be outstanding
-            if (has_lo) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (has_lo) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -904,7 +923,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         load_ktf(ktf, wl);
         if (nsl > 2) wait_all_but_one_slice();      // slice 1 landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bs_barrier();           // P2: lse', delta(0), slice 1 visible
+        bs_barrier();           // P2: constants of slice 0, slice 1 visible
         STAMP(4);
         int dsbuf = 0, slot_next = 0;      // ring slot of slice sl + 3 (== slot of slice sl); slice sl + 1 is slot_next + 1
         for (int sl = 0; sl < nsl; ++sl) {
@@ -927,21 +946,19 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         dssum = 0.f;
     } else {
         // ======== key-owning waves (and idle ones when T <= 192: they only take part in the barriers and dQ tiles) ========
-        // V fragments of this wave's 32 keys and the lse row: plain global loads, but in asm together with their wait --
+        // V fragments of this wave's 32 keys: plain global loads, but in asm together with their wait --
         // hipcc waits vmcnt(0) at the first use of a compiler-visible load while LDS-DMA requests are outstanding, and a
         // register with an asm load in flight must not be visible to it as free (an earlier version issued these loads in
         // the common code: the worker never named the registers, hipcc reused them for its address arithmetic, the landing
         // loads overwrote those, and the kernel faulted).  The wait also covers this wave's K share.
         u32x4_t vraw[4];
-        float lraw;
         {
             const bf16_t* vp = base + (size_t)min(mykey, T - 1) * rs + 2 * HH + h2 * 8;
-            const float* lp = lse + min(tid, T - 1);
-            asm volatile("global_load_dwordx4 %0, %5, off\n\tglobal_load_dwordx4 %1, %5, off offset:32\n\t"
-                         "global_load_dwordx4 %2, %5, off offset:64\n\tglobal_load_dwordx4 %3, %5, off offset:96\n\t"
-                         "global_load_dword %4, %6, off\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3]), "=&v"(lraw)
-                         : "v"(vp), "v"(lp)
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3])
+                         : "v"(vp)
                          : "memory");
         }
         STAMP(2);
@@ -955,8 +972,6 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         STAMP(3);
         bf16x8 ktf[8];
         load_ktf(ktf, lane);
-        // (rows past T: a finite stand-in for -inf, so that the split stays finite and P underflows to exactly 0)
-        if (tid < 256) bs_write_b64(smem0 + BS_STAT + tid * 16, bs_split3(tid < T ? -lraw * inv_scale : -60000.f));
         bs_barrier();           // P2
         // lane addresses of the in-loop reads.  Transposed Q / dO: rows qlo (lo) and qlo + 8 (hi) of d block db; the second
         // 16-query half is +2048 bytes and the dO image +32768 bytes from the Q image, both as instruction offsets.  Row
@@ -994,7 +1009,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                 // row fragments of Q / dO: 9 reads in issue order, consumed under counted lgkmcnt waits
                 u32x4_t stq, fa[4], fd[4];
                 {
-                    const unsigned sa = st_a + sl * 512, so = sl * 4096;
+                    const unsigned sa = st_a + (sl & 7) * 512, so = (sl & 7) * 4096;
                     asm volatile(
                         "ds_read_b128 %0, %9\n\t"
                         "ds_read_b128 %1, %10\n\tds_read_b128 %2, %10 offset:32768\n\tds_read_b128 %3, %11\n\t"
@@ -1031,7 +1046,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                 // transposed Q / dO fragments for dK / dV: requested here, consumed after the softmax arithmetic
                 tr64_t ta[8], tb[8];
                 {
-                    const unsigned so = sl * 4096;
+                    const unsigned so = (sl & 7) * 4096;
                     // per d block, order: dO lo, dO hi, Q lo, Q hi of query half 0, then the same of half 1 (+2048)
                     tr_issue8ab<32768, 32768, 0, 0, 32768 + 2048, 32768 + 2048, 2048, 2048>(tq[0][0] + so, tq[0][1] + so, ta);
                     tr_issue8ab<32768, 32768, 0, 0, 32768 + 2048, 32768 + 2048, 2048, 2048>(tq[1][0] + so, tq[1][1] + so, tb);
@@ -1142,7 +1157,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
             }
-            p.bias_partial[((size_t)(tid >> 6) * p.B + b) * HH + h * HD + d] = v;
+            p.bias_partial[((size_t)(tid >> 6) * p.B * nkb + (size_t)b * nkb + kbi) * HH + h * HD + d] = v;
         }
     }
     STAMP(27);
@@ -1162,7 +1177,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         for (int ps = 0; ps < 8; ++ps) {
             const int row = ps * 8 + (lane >> 3), ch = lane & 7;
             const uint4 v = stage_row_chunk(blk, row, ch);
-            const int key = wave * 32 + (row & 31);
+            const int key = key_base + wave * 32 + (row & 31);
             if (key < T)
                 *reinterpret_cast<uint4*>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8) = v;
         }
@@ -1211,13 +1226,25 @@ int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, bf16_t* out_lo, float* l
     return GETMI_OK;
 }
 
+// GETMI_ATTN_STREAM=0 keeps the staged kernel (key blocks of 256); default: the streamed one (one block for T <= 224, else
+// blocks of 224 keys: its eighth wave is the staging worker)
+static bool attn_bwd_streamed() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GETMI_ATTN_STREAM");
+        v = e ? (atoi(e) != 0) : 1;
+    }
+    return v != 0;
+}
+static int attn_bwd_nkb(int T) { return attn_bwd_streamed() ? (T <= 224 ? 1 : (T + 223) / 224) : (T + 255) / 256; }
 static size_t attn_bwd_slab_bytes(int B, int T, int H) {
-    const size_t n = T > 256 ? (size_t)((T + 255) / 256) * B * T * H * HD * sizeof(float) : 0;   // per-key-block dQ slabs
+    const int nkb = attn_bwd_nkb(T);
+    const size_t n = nkb > 1 ? (size_t)nkb * B * T * H * HD * sizeof(float) : 0;   // per-key-block dQ slabs
     return (n + 255) & ~(size_t)255;
 }
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H) {
     // + per-workgroup column sums of dQ and dV (bias gradients): [2][B * key blocks][H*64] fp32
-    return attn_bwd_slab_bytes(B, T, H) + (size_t)2 * B * ((T + 255) / 256) * H * HD * sizeof(float);
+    return attn_bwd_slab_bytes(B, T, H) + (size_t)2 * B * attn_bwd_nkb(T) * H * HD * sizeof(float);
 }
 int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* out2, int R, int C, int accumulate,
                          hipStream_t st);
@@ -1230,12 +1257,14 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
                         ((uintptr_t)out % 16 == 0) && ((uintptr_t)out_lo % 16 == 0) && ((uintptr_t)workspace % 256 == 0),
                     "attn_bwd: pointers must be 16-byte aligned (workspace 256)");
-    float* dq_acc = nullptr;
-    if (T > 256) dq_acc = reinterpret_cast<float*>(workspace);   // every slab element is written by its key block
+    const int nkb = attn_bwd_nkb(T);
+    float* dq_acc = nkb > 1 ? reinterpret_cast<float*>(workspace) : nullptr;   // every slab element is written by its key block
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
         attr_set = true;
     }
     const bool want_bias = dq_bias != nullptr || dv_bias != nullptr;
@@ -1247,17 +1276,8 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_
         skew_env = e ? atoi(e) : -1;
     }
     AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale, skew_env > 0 ? skew_env : 0};
-    const int nkb = (T + 255) / 256;
-    // T <= 224: the streamed-prologue kernel (GETMI_ATTN_STREAM=0 keeps the staged one)
-    static int stream_env = -1;
-    if (stream_env < 0) {
-        const char* e = getenv("GETMI_ATTN_STREAM");
-        stream_env = e ? atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
-    }
-    if (T <= 224 && stream_env != 0)      // wave 7 must be free of keys: it is the kernel's staging worker
-        hipLaunchKernelGGL(attn_bwd_stream_kernel, dim3(B * H), dim3(512), BS_LDS, st, a);
+    if (attn_bwd_streamed())
+        hipLaunchKernelGGL(attn_bwd_stream_kernel, dim3(B * H * nkb), dim3(512), BS_LDS, st, a);
     else
         hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H * nkb), dim3(512), BW_LDS, st, a);
     GETMI_CHECK_LAUNCH("attn_bwd");

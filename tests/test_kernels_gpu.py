@@ -211,8 +211,8 @@ def attn_ref(qkv, B, T, H, scale):
     return o, torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (1, 128, 3), (2, 256, 2), (1, 257, 2),
-                                   (1, 2001, 2), (1, 513, 1)])
+@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (1, 128, 3), (2, 224, 2), (2, 225, 1), (2, 256, 2),
+                                   (1, 257, 2), (1, 449, 2), (1, 2001, 2), (1, 513, 1)])
 def test_attention_fwd_bwd(K, B, T, H):
     scale = 0.125
     qkv = bf(rnd(B * T, 3 * H * 64, scale=1.5, seed=19))
@@ -242,7 +242,8 @@ def test_attention_fwd_bwd(K, B, T, H):
         assert err <= tol, f"attn.{name} err {err:.3e} > {tol:.3e}"
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (2, 70, 1), (1, 97, 2), (2, 256, 2), (1, 300, 1)])
+@pytest.mark.parametrize("B,T,H", [(2, 201, 12), (1, 32, 1), (3, 37, 2), (2, 70, 1), (1, 97, 2), (2, 256, 2), (1, 300, 1),
+                                   (1, 1000, 2)])
 def test_attention_bwd_with_output_residual(K, B, T, H):
     """out_lo path (delta from O + its rounding residual): dqkv as without it to rounding, and the q_bias sums -- a pure
     cancellation sum -- an order of magnitude closer to the fp32 reference than the 4e-3 bar of the plain path."""
@@ -444,3 +445,19 @@ def test_second_generation_gemm_kernel_stays_correct():
                             "-m", "gpu", "-k", "gemm_tn", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, (extra, r.stdout[-2000:], r.stderr[-1000:])
+
+
+def test_staged_attention_backward_stays_correct():
+    """The staged attention backward (attn_bwd_kernel: key blocks of 256, everything staged before the first slice) is kept
+    behind GETMI_ATTN_STREAM=0; the default is the streamed kernel.  The attention tests of this file are re-run under the
+    switch in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["GETMI_ATTN_STREAM"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_attention", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])

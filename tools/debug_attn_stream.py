@@ -12,7 +12,7 @@ def ref(qkv, dout, B, T, H, scale):
     o.backward(dout.float())
     return qr.grad
 
-for B, T, H, lo in ((1, 201, 1, False), (1, 201, 1, True), (2, 201, 12, False), (1, 32, 1, False), (3, 37, 2, True)):
+for B, T, H, lo in ((1, 201, 1, True), (1, 256, 1, True), (1, 513, 2, False), (1, 2001, 1, True)):
     g = torch.Generator().manual_seed(1)
     qkv = (torch.randn(B * T, 3 * H * 64, generator=g) * 1.5).bfloat16().cuda()
     dout = torch.randn(B * T, H * 64, generator=g).bfloat16().cuda()
@@ -28,5 +28,5 @@ for B, T, H, lo in ((1, 201, 1, False), (1, 201, 1, True), (2, 201, 12, False), 
         nan = torch.isnan(d[:, :, i])
         rows = nan.any(-1).any(0).any(-1).nonzero().flatten().tolist()
         e = torch.nan_to_num(e, nan=0.0)
-        per_slice = [round(e[:, t0:t0 + 32].abs().max().item(), 4) for t0 in range(0, T, 32)]
-        print(f"  {name}: nan rows {rows[:12]}{'...' if len(rows) > 12 else ''} n={len(rows)}  max|ref| {r[:, :, i].abs().max().item():.3f}  err per 32 rows {per_slice}")
+        per_slice = [round(e[:, t0:t0 + 224].abs().max().item(), 4) for t0 in range(0, T, 224)]
+        print(f"  {name}: nan rows {rows[:12]}{'...' if len(rows) > 12 else ''} n={len(rows)}  max|ref| {r[:, :, i].abs().max().item():.3f}  err per 224 rows {per_slice}")
