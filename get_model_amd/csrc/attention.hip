@@ -665,17 +665,22 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Streamed-prologue backward for T <= 256 (one key block per (b, h)).  Same arithmetic, accumulator layouts and LDS images
-// as attn_bwd_kernel; what changes is WHEN the operands arrive.  attn_bwd_kernel stages everything (K, V, all of Q, dO,
-// and the O / O_lo rows for delta: ~155 KB per workgroup) before its first slice, and at the ~10 B/clk one CU gets
-// while its single resident workgroup waits that prologue is 17-19 k of the kernel's ~47 k cycles.  Here only K, V and
-// the first slice are waited for; the Q / dO / O / O_lo rows of slice X (16 KB = two LDS-DMA instructions per wave)
-// are requested three slices ahead and land while slices X-3 .. X-1 compute:
-//     top of slice s     : request slice s+3 (its O / O_lo ring slot held slice s, whose delta was formed in slice s-1)
-//     during slice s     : delta of slice s+1 from the LDS copies (visible since barrier s-1), 4 queries per wave
-//     end of slice s     : s_waitcnt vmcnt(2) -> this wave's pieces of slice s+2 have landed; barrier s publishes them
-// Every LDS access between the first request and the last barrier is either a plain ds_read / ds_write the compiler
-// does not guard, or inline asm (transposed reads): hipcc would put vmcnt(0) in front of the tr intrinsic.
+// Streamed backward (one key block per (b, h) for T <= 224, key blocks of 224 keys above).  Same arithmetic, accumulator
+// layouts and images as attn_bwd_kernel; what changes is WHEN the operands arrive and WHO fetches them.  attn_bwd_kernel
+// stages everything (K, V, all of Q, dO, and the O / O_lo rows for delta: ~155 KB per workgroup) before its first slice,
+// and at the ~10 B/clk one CU gets while its single resident workgroup waits, that prologue was 22 k of the kernel's 54 k
+// cycles.  Here only K, V and the first slice are waited for.  Wave 7 owns no keys and is the WORKER: it requests the
+// Q / dO / O / O_lo / lse rows of slice X (16 + 1 LDS-DMA instructions) three slices ahead and forms the slice's
+// constants (-lse/scale, -delta) one slice ahead; waves 0-6 own 32 keys each and run nothing but slice arithmetic:
+//     worker, slice s    : request slice s+3 (ring slots: Q / dO / constants / lse = slice & 7, O / O_lo = slice % 3);
+//                          constants of slice s+1 from the LDS copies (visible since barrier s-1);
+//                          s_waitcnt vmcnt(17) -> slice s+2 has landed (loads return in order); barrier s publishes it
+//     key owners, slice s: S', dP' (the constants enter through one extra MFMA K step each), P, dS, dV^T, dK^T; barrier s
+//     all eight waves    : one 16 x 16 dQ^T tile of slice s each
+// Every LDS access while LDS-DMA is in flight is inline asm (hipcc guards plain LDS reads AND writes with vmcnt(0)), the
+// barriers are raw s_barrier behind lgkmcnt(0), V comes by asm global loads fused with their wait, and the two code paths
+// share no lane-derived registers (notes at the respective places: each of them was a measured stall, a wrong result or
+// a fault).  Cycle stamps: profiles/r02_attn_bwd_stream_stamps.txt.
 #define BS_STAT 131072            // [256 q][16 B]: -lse/scale and -delta of query q as three bf16 terms each (see bs_split3)
 #define BS_OSTG (131072 + 4096)   // 3 slots x (O rows 4 KiB | O_lo rows 4 KiB) of one slice
 #define BS_LSE (BS_OSTG + 3 * 8192)   // 8 slots x 64 fp32: the lse rows of a slice (+ the next 32, unused), by dword LDS-DMA
@@ -706,30 +711,6 @@ __device__ __forceinline__ u32x2_t bs_split3(float x) {
     const float r2 = r1 - __uint_as_float(l);
     return (u32x2_t){(h >> 16) | l, __float_as_uint(r2) >> 16};
 }
-// dot(4 bf16 of dO, 4 bf16 of O (+ O_lo)) of one lane; reads issued and waited here
-__device__ __forceinline__ float bs_delta_piece(unsigned ado, unsigned ao, bool has_lo) {
-    u32x2_t d, a, e;
-    if (has_lo) {
-        asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %4 offset:4096\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(d), "=&v"(a), "=&v"(e) : "v"(ado), "v"(ao) : "memory");
-    } else {
-        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(d), "=&v"(a) : "v"(ado), "v"(ao) : "memory");
-        e = (u32x2_t){0u, 0u};
-    }
-    const float a0 = bf2f(a[0] & 0xffff) + bf2f(e[0] & 0xffff), a1 = bf2f(a[0] >> 16) + bf2f(e[0] >> 16);
-    const float a2 = bf2f(a[1] & 0xffff) + bf2f(e[1] & 0xffff), a3 = bf2f(a[1] >> 16) + bf2f(e[1] >> 16);
-    return (a0 * bf2f(d[0] & 0xffff) + a1 * bf2f(d[0] >> 16)) + (a2 * bf2f(d[1] & 0xffff) + a3 * bf2f(d[1] >> 16));
-}
-// sum over the 16 lanes of a DPP row, VALU only (quad xor 1, quad xor 2, row rotate 4, row rotate 8)
-__device__ __forceinline__ float bs_row_sum16(float v) {
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true));
-    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true));
-    return v;
-}
-
 __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
