@@ -40,6 +40,16 @@ def cases():
     yield "attention fwd", lambda: res.__setitem__("a", K.attention_fwd(x3, B, T, H, 0.125)), lambda: torch.cat([res["a"][0].float().flatten(), res["a"][1].flatten()])
     yield "attention bwd", lambda: res.__setitem__("b", K.attention_bwd(x3, out, xD, lse, B, T, H, 0.125, want_bias=True)), \
         lambda: torch.cat([res["b"][0].float().flatten(), res["b"][1], res["b"][2]])
+    # as the training step calls it (rounding residual of the output), and a long context (key blocks + dQ slabs): the
+    # streamed backward orders its LDS-DMA against its readers with counted vmcnt waits only
+    out2, lse2, lo2 = K.attention_fwd(x3, B, T, H, 0.125, want_lo=True)
+    yield "attention bwd (O_lo)", lambda: res.__setitem__("c", K.attention_bwd(x3, out2, xD, lse2, B, T, H, 0.125, want_bias=True, out_lo=lo2)), \
+        lambda: torch.cat([res["c"][0].float().flatten(), res["c"][1], res["c"][2]])
+    BL, TL = 4, 2001
+    xl, dl = rb(BL * TL, 3 * H * 64), rb(BL * TL, H * 64)
+    outl, lsel, lol = K.attention_fwd(xl, BL, TL, H, 0.125, want_lo=True)
+    yield "attention bwd (T=2001)", lambda: res.__setitem__("d", K.attention_bwd(xl, outl, dl, lsel, BL, TL, H, 0.125, want_bias=True, out_lo=lol)), \
+        lambda: torch.cat([res["d"][0].float().flatten(), res["d"][1], res["d"][2]])
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
