@@ -213,6 +213,8 @@ def main():
             out = model(**model.get_input(batch))
             return (out[0] if isinstance(out, tuple) else out).float().mean()
 
+    opt_events = []      # (the optimizer step is in ms_per_step and also reported on its own)
+
     def step():
         if args.inference:
             return infer_step()
@@ -222,7 +224,11 @@ def main():
         loss = model.after_loss(model.loss(pred, obs))
         loss.backward()
         buckets.finish()
-        opt.step()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        opt.step()          # on torch's current stream, the one the events are recorded on
+        e1.record()
+        opt_events.append((e0, e1))
         return loss
 
     def fence():
@@ -241,6 +247,7 @@ def main():
     fence()
     if not args.no_kernel_events:
         K.PROFILE = []
+    opt_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -294,6 +301,7 @@ def main():
             "loss": float(loss.item()),
             "flop_per_region": fpr,
             "e2e_mfma_frac": value * fpr / (world * PEAK_BF16_TFLOPS * 1e12),
+            "optimizer_ms_per_step": (sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events)) if opt_events else None,
             "roofline": roof, "kernels": kernels,
         }
     if world > 1:
