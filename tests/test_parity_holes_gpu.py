@@ -108,6 +108,77 @@ def test_c2_full_batch_slice_against_the_oracle():
     assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
 
 
+def test_c3_full_batch_pretrain_slice_against_the_oracle():
+    """BASELINE config 3 shape (GETRegionPretrain, B=256 x N=200, 12 layers): the masked predictions of four samples
+    against the oracle run on those samples alone (device-side row compaction, mask-token blend in the embed epilogue,
+    masked head at full size)."""
+    _need_gpu()
+    from oracle import get_cpu as O
+    L, B, N = 12, 256, 200
+    sd = O.fill_state_dict("pretrain", seed=33, num_layers=L)
+    model = _model("pretrain", L, sd)
+    batch = O.make_batch(B, N, 81, kind="pretrain")
+    cb = {k: v.cuda() for k, v in batch.items()}
+    out = model(**model.get_input(cb))
+    pred, obs = model.before_loss(out, cb)
+    key = list(pred.keys())[0]
+    got_all, obs_all = pred[key].detach().float().cpu(), obs[key].detach().float().cpu()
+    cnt = batch["mask"].sum(1)
+    start = torch.cumsum(cnt, 0) - cnt
+    assert got_all.shape == (int(cnt.sum()), 283)
+    idx = [0, 101, 254, 255]
+    torch.set_num_threads(16)
+    sub = {k: v[idx] for k, v in batch.items()}
+    _, opred = O.pretrain_loss(sd, sub, num_layers=L)
+    got = torch.cat([got_all[int(start[i]):int(start[i] + cnt[i])] for i in idx])
+    assert got.shape == opred.shape
+    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    # the targets handed to the loss are the original rows of the masked regions, in the same order
+    want = torch.cat([batch["region_motif"][i][batch["mask"][i].bool()] for i in idx])
+    assert torch.equal(torch.cat([obs_all[int(start[i]):int(start[i] + cnt[i])] for i in idx]), want)
+
+
+def test_c4_long_context_atac_slice_against_the_oracle():
+    """BASELINE config 4 shape (GETRegionFinetuneATAC, B=16 x N=2000, 12 layers): two samples against the oracle, and one
+    training step at that size (streamed attention backward over nine key blocks) gives finite gradients that do not
+    depend on the other samples of the batch."""
+    _need_gpu()
+    from oracle import get_cpu as O
+    L, B, N = 12, 16, 2000
+    sd = O.fill_state_dict("atac", seed=34, num_layers=L)
+    model = _model("atac", L, sd)
+    batch = O.make_batch(B, N, 82, kind="atac")
+    cb = {k: v.cuda() for k, v in batch.items()}
+    out = model(**model.get_input(cb))
+    pred, obs = model.before_loss(out, cb)
+    key = list(pred.keys())[0]
+    idx = [0, 15]
+    torch.set_num_threads(16)
+    _, opred = O.finetune_loss(sd, {k: v[idx] for k, v in batch.items()}, kind="atac", num_layers=L)
+    got = pred[key][idx].detach().float().cpu()
+    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    loss = model.after_loss(model.loss(pred, obs))
+    loss.backward()
+    g_full = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g_full.values())
+    # the same two samples alone, loss re-weighted to their share of the batch mean: the gradient is a sum over samples,
+    # so it must equal the full-batch gradient minus the other samples' part -- checked through linearity on a 2+14 split
+    model.zero_grad(set_to_none=True)
+    parts = []
+    for sel in (idx, [i for i in range(B) if i not in idx]):
+        sb = {k: v[sel] for k, v in cb.items()}
+        o2 = model(**model.get_input(sb))
+        p2, ob2 = model.before_loss(o2, sb)
+        l2 = model.after_loss(model.loss(p2, ob2)) * (len(sel) / B)
+        l2.backward()
+    for n, p in model.named_parameters():
+        if n.endswith("attn.q_bias"):
+            continue      # a cancellation sum: compared on its own scale in test_model_parity_gpu.py
+        ref = g_full[n].float().flatten()
+        cos = F.cosine_similarity(p.grad.float().flatten(), ref, dim=0).item()
+        assert cos > 0.999, (n, cos)
+
+
 def _close(name, got, idx, vals, gsum, tol_val=6e-2, tol_norm=4e-2):
     g = got.detach().double().cpu().flatten()
     ref_scale = max(np.abs(vals).max(), gsum[1] / np.sqrt(g.numel()), 1e-20)
