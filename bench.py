@@ -143,6 +143,7 @@ def cpu_baseline(kind="finetune", N=200, forward_only=False, budget_s=25.0):
                       f"steps ({best:.3f} s/step) after 1 warm-up, {cores} threads"}
 
 
+DOMINANT_GROUP = "gemm_wgrad_kernel(+reduce_slabs)"
 MODEL_NAMES = {"finetune": "GETRegionFinetune", "pretrain": "GETRegionPretrain", "atac": "GETRegionFinetuneATAC"}
 
 
@@ -156,6 +157,9 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--all-kernel-events", action="store_true",
+                    help="bracket EVERY GEMM / attention launch with HIP events (the per-kernel table; costs ~0.9 ms per C2 "
+                         "step).  Default: only the dominant kernel group (weight-gradient GEMMs) is bracketed")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of FusedAdamW")
     ap.add_argument("--cu-limit", type=int, default=0, help="experiment: getmi_set_cu_limit before the run")
     ap.add_argument("--model", choices=["finetune", "pretrain", "atac"], default="finetune",
@@ -247,6 +251,10 @@ def main():
     fence()
     if not args.no_kernel_events:
         K.PROFILE = []
+        # The dominant kernel group of a training step is known from the committed rocprofv3 kernel statistics of this
+        # same command (profiles/r02_bench_kernel_stats.csv: weight-gradient GEMMs 20.4 % of the step, next the plain
+        # bf16 GEMMs 19.0 %), so only its launches carry events by default; forward-only runs have no wgrad: all groups.
+        K.PROFILE_ONLY = None if (args.all_kernel_events or args.inference) else {DOMINANT_GROUP}
     opt_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -281,7 +289,10 @@ def main():
             roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
                     "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r0N_pmc_traffic.json)",
-                    "launches": n, "avg_launch_us": sec / n * 1e6}
+                    "launches": n, "avg_launch_us": sec / n * 1e6,
+                    "events_on": "every GEMM / attention launch" if K.PROFILE_ONLY is None else
+                                 "this kernel group only (dominant by profiles/r02_bench_kernel_stats.csv; "
+                                 "--all-kernel-events for the table)"}
         fpr = flop_per_region(args.model, N, args.layers, args.inference)
         loss_name = "MSE" if args.model == "pretrain" else "PoissonNLL"
         if args.inference:

@@ -14,11 +14,14 @@ F32 = torch.float32
 # bench.py sets PROFILE = [] to collect (kernel name, algorithmic flops, start event, end event) per GEMM launch,
 # recorded on the stream the kernel is launched on (torch's current stream).
 PROFILE = None
+# when a set: only these kernel groups get events (an event pair per launch keeps consecutive kernels from overlapping
+# their ramp-up / tail: ~0.9 ms per C2 step with every GEMM and attention launch bracketed, ~0.2 ms with one group)
+PROFILE_ONLY = None
 _EPI_NAMES = ("bf16", "bias_gelu", "bias_resid", "dgelu", "embed", "f32", "bias_gelu", "dgelu")   # 6, 7: training forms
 
 
-def _prof_begin():
-    if PROFILE is None:
+def _prof_begin(name):
+    if PROFILE is None or (PROFILE_ONLY is not None and name not in PROFILE_ONLY):
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -89,7 +92,7 @@ def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, ro
     N = B.shape[0]
     assert B.shape[1] == K and A.dtype == BF16 and B.dtype == BF16
     ws = None if dbias is None else _ws(lib.query("getmi_gemm_tn_workspace_bytes", M, N), A.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("gemm_tn_kernel<" + _EPI_NAMES[epi] + ">")
     ldo = (out0 if out0 is not None else out1).shape[-1]
     lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, ldo, bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
@@ -109,7 +112,7 @@ def gemm_wgrad(X, Y, out=None, accumulate=False):
         accumulate = False
     nbytes = lib.query("getmi_gemm_wgrad_workspace_bytes", M, N1, N2)
     ws = _ws(nbytes, X.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("gemm_wgrad_kernel(+reduce_slabs)")
     lib.call("getmi_gemm_wgrad", X, Y, M, N1, N2, X.stride(0), Y.stride(0), out, int(accumulate), ws, ws.numel())
     _prof_end(e0, "gemm_wgrad_kernel(+reduce_slabs)", 2.0 * M * N1 * N2)
     return out
@@ -126,7 +129,7 @@ def gemm_wgrad_pair(Xa, Ya, Xb, Yb, out_a=None, out_b=None):
     if out_b is None:
         out_b = torch.empty(N1b, N2b, dtype=F32, device=Xa.device)
     ws = _ws(lib.query("getmi_gemm_wgrad_pair_workspace_bytes", M, N1a, N2a, N1b, N2b), Xa.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("gemm_wgrad_kernel(+reduce_slabs)")
     lib.call("getmi_gemm_wgrad_pair", Xa, Ya, N1a, N2a, Xa.stride(0), Ya.stride(0), out_a, 0, Xb, Yb, N1b, N2b, Xb.stride(0),
              Yb.stride(0), out_b, 0, M, ws, ws.numel())
     _prof_end(e0, "gemm_wgrad_kernel(+reduce_slabs)", 2.0 * M * (N1a * N2a + N1b * N2b))
@@ -168,7 +171,7 @@ def attention_fwd(qkv, B, T, H, scale, want_lo=False):
     out = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device)
     lo = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device) if want_lo else None
     lse = torch.empty(B, H, T, dtype=F32, device=qkv.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("attn_fwd_kernel")
     lib.call("getmi_attention_fwd", qkv, out, lo, lse, B, T, H, float(scale))
     _prof_end(e0, "attn_fwd_kernel", 4.0 * B * H * T * T * 64)
     return (out, lse, lo) if want_lo else (out, lse)
@@ -181,7 +184,7 @@ def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False, out_lo=N
     dqb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     dvb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin("attn_bwd_kernel(+delta)")
     lib.call("getmi_attention_bwd", qkv, out, out_lo, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), ws, ws.numel())
     _prof_end(e0, "attn_bwd_kernel(+delta)", 10.0 * B * H * T * T * 64)
     return (dqkv, dqb, dvb) if want_bias else dqkv
