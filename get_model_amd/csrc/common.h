@@ -32,8 +32,11 @@ __device__ __forceinline__ uint2 pack4bf(float a, float b, float c, float d) {
 
 // 16-byte asynchronous global -> LDS copy (global_load_lds_dwordx4). LDS destination = lds_wave_base +
 // lane*16 (wave-uniform base), global source is per lane.
+#ifndef GETMI_GLDS_AUX
+#define GETMI_GLDS_AUX 0        // cache-policy bits of the LDS-DMA loads (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); experiment switch
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, GETMI_GLDS_AUX);
 }
 
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (bid % 8 equal) get a
