@@ -16,6 +16,7 @@
 //            over all 256 keys -> no cross-wave or cross-workgroup reduction when T <= 256 (per-key-block fp32
 //            slabs summed by a small kernel otherwise).
 #include "common.h"
+static constexpr bool kNtAttn = GETMI_NT_ATTN != 0;    // outputs are streamed (see common.h)
 #include <stdlib.h>
 
 #define HD 64
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
             const int row = ps * 8 + (lane >> 3), ch = lane & 7;
             const uint4 v = stage_row_chunk(blk, row, ch);
             if (q0 + row < T)
-                *reinterpret_cast<uint4*>(p.out + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8) = v;
+                store_u4<kNtAttn>(p.out + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8, v);
         }
         if (p.out_lo != nullptr) {
             // what the bf16 rounding of O dropped: the backward forms delta = rowsum(dO * O) from out + out_lo
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
                 const int row = ps * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = stage_row_chunk(blk, row, ch);
                 if (q0 + row < T)
-                    *reinterpret_cast<uint4*>(p.out_lo + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8) = v;
+                    store_u4<kNtAttn>(p.out_lo + ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8, v);
             }
         }
     }
@@ -548,14 +549,13 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                 const int d0 = dblk * 16 + (lane >> 4) * 4;
                 if (q < T) {
                     if (p.dq_acc == nullptr) {
-                        *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
-                            pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+                        store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
                     } else {
                         // long context: this key block's partial dQ goes to its own fp32 slab (plain 16-byte
                         // stores; fp32 atomics measured 2.5 ms per call at T = 2001), summed by attn_dq_convert
                         float* dst = p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * (H * HD) + h * HD + d0;
-                        *reinterpret_cast<float4*>(dst) = make_float4(acc[0] * p.scale, acc[1] * p.scale,
-                                                                      acc[2] * p.scale, acc[3] * p.scale);
+                        store_f4<kNtAttn>(dst, make_float4(acc[0] * p.scale, acc[1] * p.scale,
+                                                                      acc[2] * p.scale, acc[3] * p.scale));
                     }
                 }
             }
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             const uint4 v = stage_row_chunk(blk, row, ch);
             const int key = key_base + wave * 32 + (row & 31);
             if (key < T)
-                *reinterpret_cast<uint4*>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * H * HD + h * HD +
-                                          ch * 8) = v;
+                store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * H * HD + h * HD +
+                                          ch * 8, v);
         }
     }
     STAMP(28);
@@ -795,11 +795,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         const int d0 = dblk * 16 + (ln >> 4) * 4;
         if (q < T) {
             if (p.dq_acc == nullptr)
-                *reinterpret_cast<uint2*>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0) =
-                    pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+                store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
             else      // several key blocks: this block's partial dQ goes to its own fp32 slab, summed by attn_dq_convert
-                *reinterpret_cast<float4*>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0) =
-                    make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+                store_f4<kNtAttn>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0, make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
         }
     };
 
@@ -1160,7 +1158,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             const uint4 v = stage_row_chunk(blk, row, ch);
             const int key = key_base + wave * 32 + (row & 31);
             if (key < T)
-                *reinterpret_cast<uint4*>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8) = v;
+                store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8, v);
         }
     }
     STAMP(28);
@@ -1178,7 +1176,7 @@ __global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __
             const float4 w = *reinterpret_cast<const float4*>(acc + ((size_t)kb * n4 + i) * 4);
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
-        *reinterpret_cast<uint2*>(dqkv + tok * (size_t)(3 * H * HD) + rem * 4) = pack4bf(v.x, v.y, v.z, v.w);
+        store_u2<kNtAttn>(dqkv + tok * (size_t)(3 * H * HD) + rem * 4, pack4bf(v.x, v.y, v.z, v.w));
     }
 }
 

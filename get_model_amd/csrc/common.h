@@ -39,6 +39,48 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, GETMI_GLDS_AUX);
 }
 
+// Streaming ("nt") stores / loads for data the storing kernel does not read again: the line is not kept in the XCD's L2
+// ahead of the operands that ARE reused there (measured on the persistent GEMM epilogue: -0.45 ms per C2 step).
+// Elsewhere it LOSES, because the next kernel finds the data on chip when it was stored normally (same A/B, ms per step):
+// GEMM epilogue only 35.01; + LayerNorm loads/stores + attention outputs + wgrad slabs 35.50; without the LayerNorm part
+// 35.32, without the attention part 35.41, without the slab part 35.11.  So these three stay OFF (switches for A/B builds).
+#ifndef GETMI_NT_LN
+#define GETMI_NT_LN 0
+#endif
+#ifndef GETMI_NT_ATTN
+#define GETMI_NT_ATTN 0
+#endif
+#ifndef GETMI_NT_SLAB
+#define GETMI_NT_SLAB 0
+#endif
+typedef __attribute__((ext_vector_type(4))) float nt_f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned nt_u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned nt_u32x4;
+template <bool NT> __device__ __forceinline__ void store_f4(float* p, float4 v) {
+    if constexpr (NT) __builtin_nontemporal_store((nt_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f32x4*>(p));
+    else *reinterpret_cast<float4*>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void store_u2(void* p, uint2 v) {
+    if constexpr (NT) __builtin_nontemporal_store((nt_u32x2){v.x, v.y}, reinterpret_cast<nt_u32x2*>(p));
+    else *reinterpret_cast<uint2*>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void store_u4(void* p, uint4 v) {
+    if constexpr (NT) __builtin_nontemporal_store((nt_u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(p));
+    else *reinterpret_cast<uint4*>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ float4 load_f4(const float* p) {
+    if constexpr (NT) {
+        const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT> __device__ __forceinline__ uint2 load_u2(const void* p) {
+    if constexpr (NT) {
+        const nt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(p));
+        return make_uint2(v[0], v[1]);
+    } else return *reinterpret_cast<const uint2*>(p);
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks that share an XCD (bid % 8 equal) get a
 // contiguous range of logical ids, so neighbouring tiles hit the same per-XCD L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

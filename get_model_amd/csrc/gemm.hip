@@ -492,11 +492,41 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = (unsigned long long)ptr;
     return (u32x4){(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
 }
+// Cache policy of the persistent epilogue's output stores.  Streamed (" nt"): a round of 32 output tiles per XCD writes 4-8 MiB,
+// the size of the XCD's L2, and evicted the operand blocks that are reused there; streamed stores leave them alone.
+// Interleaved A/B in the C2 step, all epilogues alike: "" 34.29, " nt" 33.81, " sc1" 34.19, " sc0 sc1" 34.23,
+// " sc0 sc1 nt" 33.93, " sc1 nt" 33.88, " sc0 nt" 33.86 ms.  Per epilogue (1 = streamed): GETMI_NT_EPI_{BF16,RESID,GELU,DGELU};
+// taking one class out of the streamed set costs: GELU pair +0.37 ms, plain bf16 +0.15 (streaming only the outputs wider than
+// 1024 columns: +0.13), dGELU form +0.10, fp32 residual -0.04 (so that one is stored normally: LayerNorm reads it next);
+// streaming the epilogue's own READS (residual, stored derivative) costs +0.55.
+#ifndef GETMI_NT_EPI_BF16
+#define GETMI_NT_EPI_BF16 1
+#endif
+#ifndef GETMI_NT_EPI_RESID
+#define GETMI_NT_EPI_RESID 0
+#endif
+#ifndef GETMI_NT_EPI_GELU
+#define GETMI_NT_EPI_GELU 1
+#endif
+#ifndef GETMI_NT_EPI_DGELU
+#define GETMI_NT_EPI_DGELU 1
+#endif
+#ifndef GETMI_NT_EPI_LOADS
+#define GETMI_NT_EPI_LOADS 0     // the epilogue's own global reads (fp32 residual, stored GELU derivative)
+#endif
+template <int EPI> struct EpiNt {
+    static constexpr bool value = EPI == EPI_BIAS_RESID ? (GETMI_NT_EPI_RESID != 0)
+                                : EpiKind<EPI>::gelu    ? (GETMI_NT_EPI_GELU != 0)
+                                : EpiKind<EPI>::dgelu   ? (GETMI_NT_EPI_DGELU != 0)
+                                : EPI == EPI_BF16       ? (GETMI_NT_EPI_BF16 != 0) : false;
+};
 __device__ __forceinline__ void st_b64(u32x2 v, unsigned off, u32x4 rs) {
     asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
 }
+template <bool NT = false>
 __device__ __forceinline__ void st_b128(u32x4 v, unsigned off, u32x4 rs) {
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+    if constexpr (NT) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
+    else asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(rs) : "memory");
 }
 __device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
     return (u32x2){pack2bf(a, b), pack2bf(c, d)};
@@ -599,7 +629,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
                         const int m = min(m0w + (half * 4 + a) * 16 + ps * 8 + rrow, p.M - 1);
-                        rv[a][bp][ps] = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldo +
+                        rv[a][bp][ps] = load_f4<GETMI_NT_EPI_LOADS != 0>(p.resid + (size_t)m * p.ldo +
                                                                          min(n0w + bp * 32 + rch * 4, p.N - 4));
                     }
             }
@@ -627,7 +657,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                         const f32x4 t = __builtin_bit_cast(f32x4, dd[ps]);
                         const float4 q = rv[a][bp][ps];
                         const f32x4 o = {q.x + t[0], q.y + t[1], q.z + t[2], q.w + t[3]};
-                        st_b128(__builtin_bit_cast(u32x4, o), off, rs0);
+                        st_b128<EpiNt<EPI>::value>(__builtin_bit_cast(u32x4, o), off, rs0);
                     }
                 }
         }
@@ -645,8 +675,8 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    uv[a][b] = *reinterpret_cast<const uint2*>(p.aux + (size_t)min(em + (half * 4 + a) * 16, p.M - 1) * p.ldaux +
-                                                               min(en + b * 16, p.N - 4));
+                    uv[a][b] = load_u2<GETMI_NT_EPI_LOADS != 0>(p.aux + (size_t)min(em + (half * 4 + a) * 16, p.M - 1) * p.ldaux +
+                                                                min(en + b * 16, p.N - 4));
         }
 #pragma unroll
         for (int a = 0; a < (half ? RB1 : 4); ++a) {
@@ -689,7 +719,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                     const int row = ps * 8 + rrow;
                     const int m = m0w + ab * 16 + row, n = n0w + rch * 8;
                     const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 2) : OOB_OFF;
-                    st_b128(dd[ps], off, outp == 0 ? rs0 : rs1);
+                    st_b128<EpiNt<EPI>::value>(dd[ps], off, outp == 0 ? rs0 : rs1);
                 }
             }
         }
@@ -1598,8 +1628,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad256_kernel(WgradArgs pa) {
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            *reinterpret_cast<float4*>(out + (size_t)(e1 + a * 16) * p.N2 + e2 + b * 16) =
-                make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+            store_f4<GETMI_NT_SLAB != 0>(out + (size_t)(e1 + a * 16) * p.N2 + e2 + b * 16,
+                                         make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]));
 }
 
 // out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]        (n % 4 == 0)

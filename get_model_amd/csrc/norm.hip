@@ -9,6 +9,7 @@
 //     partial[blk] = column sums over the block's rows of {dy*xhat, dy, dz}
 // Algorithmic bytes per row (D=768): fwd 4*D read + 2*D write; bwd (2+4+4)*D read + (4+2)*D write.
 #include "common.h"
+static constexpr bool kNtLn = GETMI_NT_LN != 0;    // activations are streamed: read once, written once
 
 template <int NV>  // D = NV * 256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            a[v] = *reinterpret_cast<const float4*>(xr + (v * 64 + lane) * 4);
+            a[v] = load_f4<kNtLn>(xr + (v * 64 + lane) * 4);
             s += a[v].x + a[v].y + a[v].z + a[v].w;
         }
         const float mu = wave_sum(s) * (1.0f / D);
@@ -43,9 +44,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         bf16_t* yr = y + (size_t)row * D;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
-            *reinterpret_cast<uint2*>(yr + (v * 64 + lane) * 4) =
-                pack4bf(a[v].x * rs * g[v].x + bt[v].x, a[v].y * rs * g[v].y + bt[v].y,
-                        a[v].z * rs * g[v].z + bt[v].z, a[v].w * rs * g[v].w + bt[v].w);
+            store_u2<kNtLn>(yr + (v * 64 + lane) * 4,
+                            pack4bf(a[v].x * rs * g[v].x + bt[v].x, a[v].y * rs * g[v].y + bt[v].y,
+                                    a[v].z * rs * g[v].z + bt[v].z, a[v].w * rs * g[v].w + bt[v].w));
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         nrs = rstd[r];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            nx[v] = *reinterpret_cast<const float4*>(x + (size_t)r * D + (v * 64 + lane) * 4);
-            nd[v] = *reinterpret_cast<const uint2*>(dy + (size_t)r * D + (v * 64 + lane) * 4);
-            if (dres) nr[v] = *reinterpret_cast<const float4*>(dres + (size_t)r * D + (v * 64 + lane) * 4);
+            nx[v] = load_f4<kNtLn>(x + (size_t)r * D + (v * 64 + lane) * 4);
+            nd[v] = load_u2<kNtLn>(dy + (size_t)r * D + (v * 64 + lane) * 4);
+            if (dres) nr[v] = load_f4<kNtLn>(dres + (size_t)r * D + (v * 64 + lane) * 4);
         }
     };
     if (row < M) issue(row);
@@ -116,10 +117,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             float4 o = make_float4(rs * (d[v].x - c1 - xh[v].x * c2), rs * (d[v].y - c1 - xh[v].y * c2),
                                    rs * (d[v].z - c1 - xh[v].z * c2), rs * (d[v].w - c1 - xh[v].w * c2));
             o.x += rv[v].x; o.y += rv[v].y; o.z += rv[v].z; o.w += rv[v].w;
-            *reinterpret_cast<float4*>(dx + (size_t)row * D + (v * 64 + lane) * 4) = o;
+            store_f4<kNtLn>(dx + (size_t)row * D + (v * 64 + lane) * 4, o);
             if (dz) {
                 const float4 z = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
-                *reinterpret_cast<uint2*>(dz + (size_t)row * D + (v * 64 + lane) * 4) = pack4bf(z.x, z.y, z.z, z.w);
+                store_u2<kNtLn>(dz + (size_t)row * D + (v * 64 + lane) * 4, pack4bf(z.x, z.y, z.z, z.w));
                 az[v].x += z.x; az[v].y += z.y; az[v].z += z.z; az[v].w += z.w;
             }
         }
