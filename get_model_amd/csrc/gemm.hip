@@ -514,6 +514,9 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes) {
 #ifndef GETMI_NT_EPI_LOADS
 #define GETMI_NT_EPI_LOADS 0     // the epilogue's own global reads (fp32 residual, stored GELU derivative)
 #endif
+#ifndef GETMI_NT_EPI_RESID_LOAD
+#define GETMI_NT_EPI_RESID_LOAD GETMI_NT_EPI_LOADS
+#endif
 template <int EPI> struct EpiNt {
     static constexpr bool value = EPI == EPI_BIAS_RESID ? (GETMI_NT_EPI_RESID != 0)
                                 : EpiKind<EPI>::gelu    ? (GETMI_NT_EPI_GELU != 0)
@@ -629,7 +632,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
 #pragma unroll
                     for (int ps = 0; ps < 2; ++ps) {
                         const int m = min(m0w + (half * 4 + a) * 16 + ps * 8 + rrow, p.M - 1);
-                        rv[a][bp][ps] = load_f4<GETMI_NT_EPI_LOADS != 0>(p.resid + (size_t)m * p.ldo +
+                        rv[a][bp][ps] = load_f4<GETMI_NT_EPI_RESID_LOAD != 0>(p.resid + (size_t)m * p.ldo +
                                                                          min(n0w + bp * 32 + rch * 4, p.N - 4));
                     }
             }
