@@ -498,7 +498,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes) {
 // " sc0 sc1 nt" 33.93, " sc1 nt" 33.88, " sc0 nt" 33.86 ms.  Per epilogue (1 = streamed): GETMI_NT_EPI_{BF16,RESID,GELU,DGELU};
 // taking one class out of the streamed set costs: GELU pair +0.37 ms, plain bf16 +0.15 (streaming only the outputs wider than
 // 1024 columns: +0.13), dGELU form +0.10, fp32 residual -0.04 (so that one is stored normally: LayerNorm reads it next);
-// streaming the epilogue's own READS (residual, stored derivative) costs +0.55.
+// streaming the epilogue's own READS (residual, stored derivative) costs +0.55 (the residual reads alone: +-0); streaming only
+// the derivative of the GELU pair and storing gelu(u) normally for the fc2 GEMM that follows: +0.07.
 #ifndef GETMI_NT_EPI_BF16
 #define GETMI_NT_EPI_BF16 1
 #endif
