@@ -505,11 +505,21 @@ int getmi_scale_cast_noalloc_impl(const float* dx, const float* rowscale, int ro
 
 int getmi_head_fwd_impl(const bf16_t* hf, const float* W, const float* bias, float* logits, float* pred, int B, int N,
                         int D, int OUT, hipStream_t st) {
-    GETMI_CHECK_ARG(D == 768, "head_fwd: D=%d unsupported (768)", D);
+    GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "head_fwd: D=%d unsupported (256, 512, 768, 1024)", D);
     GETMI_CHECK_ARG(OUT == 1 || OUT == 2, "head_fwd: output_dim=%d unsupported (1 or 2)", OUT);
     const int g = rows_grid(B * N);
-    if (OUT == 1) hipLaunchKernelGGL((head_fwd_kernel<3, 1>), dim3(g), dim3(256), 0, st, hf, W, bias, logits, pred, B, N);
-    else hipLaunchKernelGGL((head_fwd_kernel<3, 2>), dim3(g), dim3(256), 0, st, hf, W, bias, logits, pred, B, N);
+#define HEAD_FWD(NV)                                                                                                      \
+    do {                                                                                                                  \
+        if (OUT == 1) hipLaunchKernelGGL((head_fwd_kernel<NV, 1>), dim3(g), dim3(256), 0, st, hf, W, bias, logits, pred, B, N); \
+        else hipLaunchKernelGGL((head_fwd_kernel<NV, 2>), dim3(g), dim3(256), 0, st, hf, W, bias, logits, pred, B, N);    \
+    } while (0)
+    switch (D / 256) {
+        case 1: HEAD_FWD(1); break;
+        case 2: HEAD_FWD(2); break;
+        case 3: HEAD_FWD(3); break;
+        default: HEAD_FWD(4); break;
+    }
+#undef HEAD_FWD
     GETMI_CHECK_LAUNCH("head_fwd");
     return GETMI_OK;
 }
@@ -522,13 +532,23 @@ size_t getmi_head_bwd_workspace_bytes_impl(int B, int N, int D, int OUT) {
 int getmi_head_bwd_impl(const float* dpred, const float* logits, const bf16_t* hf, const float* W, bf16_t* dh,
                         float* dwb, int accumulate, int B, int N, int D, int OUT, void* ws, size_t ws_bytes,
                         hipStream_t st) {
-    GETMI_CHECK_ARG(D == 768, "head_bwd: D=%d unsupported (768)", D);
+    GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "head_bwd: D=%d unsupported (256, 512, 768, 1024)", D);
     GETMI_CHECK_ARG(OUT == 1 || OUT == 2, "head_bwd: output_dim=%d unsupported (1 or 2)", OUT);
     GETMI_CHECK_ARG(ws_bytes >= getmi_head_bwd_workspace_bytes_impl(B, N, D, OUT), "head_bwd: workspace too small");
     const int g = rows_grid(B * (N + 1));
     float* partial = reinterpret_cast<float*>(ws);
-    if (OUT == 1) hipLaunchKernelGGL((head_bwd_kernel<3, 1>), dim3(g), dim3(256), 0, st, dpred, logits, hf, W, dh, partial, B, N);
-    else hipLaunchKernelGGL((head_bwd_kernel<3, 2>), dim3(g), dim3(256), 0, st, dpred, logits, hf, W, dh, partial, B, N);
+#define HEAD_BWD(NV)                                                                                                      \
+    do {                                                                                                                  \
+        if (OUT == 1) hipLaunchKernelGGL((head_bwd_kernel<NV, 1>), dim3(g), dim3(256), 0, st, dpred, logits, hf, W, dh, partial, B, N); \
+        else hipLaunchKernelGGL((head_bwd_kernel<NV, 2>), dim3(g), dim3(256), 0, st, dpred, logits, hf, W, dh, partial, B, N); \
+    } while (0)
+    switch (D / 256) {
+        case 1: HEAD_BWD(1); break;
+        case 2: HEAD_BWD(2); break;
+        case 3: HEAD_BWD(3); break;
+        default: HEAD_BWD(4); break;
+    }
+#undef HEAD_BWD
     GETMI_CHECK_LAUNCH("head_bwd");
     return getmi_colreduce_impl(partial, dwb, nullptr, nullptr, g, OUT * D + OUT, accumulate, st);
 }
