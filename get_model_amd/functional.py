@@ -557,6 +557,15 @@ class FusedLoss(torch.autograd.Function):
     def forward(ctx, pred, obs, kind, weight, eps):
         _need_gpu(pred)
         C = pred.shape[-1]
+        if pred.numel() == 0:
+            # no row to reduce over (a pre-training batch without a masked region): the reference's mean-reduced
+            # torch.nn.MSELoss / PoissonNLLLoss return NaN for empty inputs, and so does this
+            ctx.save_for_backward(torch.zeros_like(pred, dtype=torch.float32).reshape(-1, max(C, 1)))
+            ctx.weight = float(weight)
+            ctx.shape = pred.shape
+            ctx.empty = True
+            return torch.full((), float("nan"), dtype=torch.float32, device=pred.device)
+        ctx.empty = False
         p2 = pred.detach().reshape(-1, C)
         o2 = obs.detach().to(torch.float32).reshape(-1, C)
         if p2.stride(-1) != 1:
@@ -572,5 +581,7 @@ class FusedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (grad,) = ctx.saved_tensors
+        if ctx.empty:
+            return grad.view(ctx.shape), None, None, None, None
         d = K.scale_by_scalar(grad, gout.contiguous().float(), ctx.weight)
         return d.view(ctx.shape), None, None, None, None
