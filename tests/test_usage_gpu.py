@@ -90,3 +90,58 @@ def test_usage(probe):
         pytest.skip("no GPU")
     r = probe()
     assert r is True or r is None, r
+
+
+def test_autocast_context_changes_nothing():
+    """The reference trains under bf16 autocast (Lightning precision); the fused path already computes in bf16 with fp32
+    accumulation and must give the same loss and gradients inside the context."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    m, sd = mk("finetune")
+    d = {k: v.cuda() for k, v in O.make_batch(2, 30, 1).items()}
+    l0, _ = step(m, d)
+    l0.backward()
+    g0 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        l1, _ = step(m, d)
+    l1.backward()
+    assert l1.dtype == torch.float32 and float(l1.detach()) == float(l0.detach())
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, g0[n]), n
+
+
+def test_torch_ddp_wrapper_on_rccl_world_of_one():
+    """The reference's harness wraps the model in torch's DistributedDataParallel (utils.py:41-51, via Lightning): the fused
+    autograd functions must work under it (its reducer hooks, its bucket views adopted as .grad) for two consecutive steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29541"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m, sd = mk("finetune")
+        b = O.make_batch(2, 30, 1)
+        d = {k: v.cuda() for k, v in b.items()}
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=True)
+        torch.set_num_threads(16)
+        _, _, og = O.loss_and_grads("finetune", sd, b, num_layers=2, drop_path_rate=0.0)
+        for it in range(2):
+            ddp.zero_grad(set_to_none=(it == 0))
+            out = ddp(**m.get_input(d))
+            pred, obs = m.before_loss(out, d)
+            m.after_loss(m.loss(pred, obs)).backward()
+            for n, p in m.named_parameters():
+                if float(og[n].norm()) < 1e-9 or n.endswith("q_bias"):
+                    continue
+                assert p.grad is not None, n
+                cos = F.cosine_similarity(p.grad.flatten().cpu(), og[n].flatten(), dim=0).item()
+                rel = float(p.grad.cpu().norm() / og[n].norm())
+                assert cos >= 0.99 and abs(rel - 1) <= 0.05, (it, n, cos, rel)
+    finally:
+        dist.destroy_process_group()
