@@ -487,7 +487,15 @@ static int scale_cast_scratch(float** out) {
     return GETMI_OK;
 }
 
-size_t getmi_scale_cast_noalloc_max_bytes_impl(void) { return SCALE_CAST_SCRATCH_BYTES; }
+// Also the entry point's SET-UP call: it resolves the buffer address for the current device.  hipGetSymbolAddress may
+// load the code object and is not a stream operation, so it must not happen for the first time inside a HIP graph
+// capture; callers query this limit once per device at start-up (outside capture), after which every
+// getmi_scale_cast_noalloc call on that device is two kernel launches and nothing else.
+size_t getmi_scale_cast_noalloc_max_bytes_impl(void) {
+    float* unused = nullptr;
+    (void)scale_cast_scratch(&unused);
+    return SCALE_CAST_SCRATCH_BYTES;
+}
 
 int getmi_scale_cast_noalloc_impl(const float* dx, const float* rowscale, int rows_per_sample, bf16_t* dz, float* dbias,
                                   int accumulate, int M, int D, hipStream_t st) {

@@ -87,7 +87,9 @@ class GradBuckets:
     # ---- per step ----
     def zero_grad(self):
         """Start a new step: gradients are dropped (set to None), not zero-filled; slots of parameters that end
-        the step without a gradient are zeroed in finish()."""
+        the step without a gradient are zeroed in finish().  Also closes a step that never reached finish() (an
+        exception in backward): pending exchanges are waited for and the CU limit is lifted."""
+        self._drain()
         for b in self.buckets:
             for p in b:
                 p.grad = None
@@ -102,6 +104,17 @@ class GradBuckets:
         self._stray = [[] for _ in self.buckets]
         self._cb_queued = False
         self._handles = []
+
+    def _drain(self):
+        """Wait for every exchange in flight and give the compute kernels all CUs back."""
+        for h, flat in getattr(self, "_handles", []):
+            h.wait()
+            if flat is not None:
+                flat.div_(self.world)
+        self._handles = []
+        if self._cu_limited:        # the exchange is ordered before everything launched from here on
+            set_cu_limit(0)
+            self._cu_limited = False
 
     def _launch(self, bi):
         self._launched[bi] = True
@@ -127,7 +140,11 @@ class GradBuckets:
         g = p.grad
         bi = self._bucket_of[p]
         p._getmi_slot_taken = False      # this backward is done with the parameter: the slot may be handed out again
-        if self._remaining[bi] <= 0 and self.sync and self._launched[bi]:
+        if not self._cb_queued:          # once per backward pass: flush / re-arm when the pass ends (_end_of_backward)
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        # (world 1: nothing is exchanged, so a second backward before finish() is plain gradient accumulation)
+        if self._remaining[bi] <= 0 and self.sync and self._launched[bi] and self.world > 1:
             raise RuntimeError("ddp.GradBuckets: a gradient arrived for a bucket that was already exchanged in this step "
                                "(a second backward without finish()? use sync=False for micro-batches)")
         if g.data_ptr() != view.data_ptr() or g.stride() != view.stride():
@@ -135,9 +152,6 @@ class GradBuckets:
             # bucket by ONE multi-tensor copy when the bucket completes, instead of a copy launch per parameter
             self._stray[bi].append((view, g))
             p.grad = view
-            if not self._cb_queued:      # buckets that stay incomplete (unused parameters) are flushed when this
-                self._cb_queued = True   # backward pass ends, so a following accumulate-backward sees real data
-                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         self._remaining[bi] -= 1
         if self._remaining[bi] == 0:
             self._flush(bi)
@@ -145,9 +159,15 @@ class GradBuckets:
                 self._launch(bi)
 
     def _end_of_backward(self):
+        """End of one backward pass: buckets that stayed incomplete (unused parameters) are flushed, so a following
+        accumulate-backward sees real data; after a sync=False micro-batch the per-bucket countdown is re-armed, so the
+        LAST micro-batch (sync=True) launches each bucket's exchange as it completes instead of deferring all of them
+        to finish()."""
         self._cb_queued = False
         for bi in range(len(self.buckets)):
             self._flush(bi)
+        if not any(self._launched):
+            self._remaining = [len(b) for b in self.buckets]
 
     def _flush(self, bi):
         stray = self._stray[bi]
@@ -168,14 +188,7 @@ class GradBuckets:
             self._flush(bi)
             if not self._launched[bi]:
                 self._launch(bi)
-        for h, flat in self._handles:
-            h.wait()
-            if flat is not None:
-                flat.div_(self.world)
-        self._handles = []
-        if self._cu_limited:        # the exchange is ordered before everything launched from here on
-            set_cu_limit(0)
-            self._cu_limited = False
+        self._drain()
         # the step's bookkeeping ends here, whichever zero_grad the training loop calls next (optimizer.zero_grad()
         # leaves this object alone; with stale counters no bucket would ever be exchanged again and ranks would diverge)
         self._begin_step()
@@ -194,7 +207,7 @@ def set_cu_limit(n):
     return lib.query("getmi_set_cu_limit", int(n))
 
 
-def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
+def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64), total_cus=None):
     """Measure, on this node, how the gradient exchange should share the GPU with backward, and leave the winner set.
 
     Candidates: all-reduces overlapped with backward on all CUs; overlapped with `r` CUs left to RCCL's channel
@@ -203,7 +216,8 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
     settling step and `steps` timed steps of `step_fn` (a full training step incl. buckets.finish()); ranks agree on
     the maximum time.  The CU limit applies only while an exchange is in flight (GradBuckets.cu_limit_during_exchange).
     Returns {"overlap": bool, "cu_limit": int, "ms": {candidate: ms_per_step}}.
-    world_size 1: nothing to tune."""
+    world_size 1: nothing to tune.  total_cus: CU count to derive the limited candidates from (default: asked of the
+    device; the gloo tests pass it to rehearse those candidates without a GPU)."""
     import time
     result = {"overlap": True, "cu_limit": 0, "ms": {}}
     if buckets.world == 1:
@@ -214,7 +228,9 @@ def autotune(step_fn, buckets, steps=2, reserve_options=(16, 32, 64)):
         from . import lib
         set_cu_limit(0)
         total = lib.query("getmi_cu_count")
-    cands = [(True, 0)] + [(True, total - r) for r in reserve_options if gpu and total - r >= 64] + [(False, 0)]
+    if total_cus is not None:
+        total = int(total_cus)
+    cands = [(True, 0)] + [(True, total - r) for r in reserve_options if total - r >= 64] + [(False, 0)]
 
     def fence():
         if gpu:

@@ -289,7 +289,13 @@ class ConcatCLS(torch.autograd.Function):
 
 
 def concat_cls(x, cls_token):
-    return ConcatCLS.apply(x, cls_token, bool(getattr(x, "_getmi_token_rows", False)))
+    in_place = bool(getattr(x, "_getmi_token_rows", False))
+    full = ConcatCLS.apply(x, cls_token, in_place)
+    if in_place:
+        # row 0 behind x now belongs to `full`: a second concat_cls on the same region_embed output (two towers, another
+        # cls_token) must take the copy path instead of overwriting the CLS row under the first result
+        x._getmi_token_rows = False
+    return full
 
 
 # --------------------------------------------------------------------------------------------
@@ -451,6 +457,57 @@ class ExpressionHeadSoftplus(torch.autograd.Function):
         B, T, D = ctx.dims
         dh, dW, db = K.head_bwd(dpred.contiguous().float(), logits, hf2, Wd, B, T - 1)
         return dh.view(B, T, D), dW, db
+
+
+class HeadLinear(torch.autograd.Function):
+    """logits[..., out] = x[..., D] @ W^T + b for ANY float GPU tensor x: the reference's stand-alone
+    `ExpressionHead.forward` contract (model/modules.py:255-258: a plain nn.Linear on [B,N,D], no CLS handling, no
+    Softplus).  Off the training path (the models call the fused ExpressionHeadSoftplus); same GEMM kernels."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        _need_gpu(x)
+        D = x.shape[-1]
+        out_dim = W.shape[0]
+        if W.shape[1] != D or D % 64 != 0:
+            raise RuntimeError(f"HeadLinear: last dimension {D} does not match the head weight {tuple(W.shape)} "
+                               f"(or is not a multiple of 64)")
+        x2 = x.detach().reshape(-1, D)
+        xb = x2.contiguous() if x2.dtype == BF16 else K.cast_pad(x2.float().contiguous(), D)
+        M = xb.shape[0]
+        Np = _pad_to(out_dim, 4)
+        ctx.dims = (tuple(x.shape), out_dim, x.dtype)
+        ctx.W = W
+        ctx.save_for_backward(xb)
+        if M == 0:
+            return torch.zeros(*x.shape[:-1], out_dim, dtype=torch.float32, device=x.device)
+        bd = b.detach().float()
+        bp = bd if Np == out_dim else torch.cat([bd, bd.new_zeros(Np - out_dim)])
+        out = torch.empty(M, Np, dtype=torch.float32, device=x.device)
+        K.gemm_tn(K.EPI_F32, xb, w_rows_padded(W, Np), out, bias=bp.contiguous())
+        return out[:, :out_dim].reshape(*x.shape[:-1], out_dim)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xb,) = ctx.saved_tensors
+        W = ctx.W
+        shape, out_dim, in_dtype = ctx.dims
+        D = shape[-1]
+        M = xb.shape[0]
+        dev = dout.device
+        if M == 0:
+            return (torch.zeros(shape, dtype=in_dtype, device=dev), torch.zeros_like(W),
+                    torch.zeros(out_dim, dtype=torch.float32, device=dev))
+        Kp = _pad_to(out_dim, 64)
+        dop = K.cast_pad(dout.reshape(M, out_dim).contiguous().float(), Kp)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxb = torch.empty(M, D, dtype=BF16, device=dev)
+            K.gemm_tn(K.EPI_BF16, dop, w_t_cols_padded(W, Kp), dxb)
+            dx = dxb.to(in_dtype).reshape(shape)
+        dW = K.gemm_wgrad(dop, xb)[:out_dim] if ctx.needs_input_grad[1] else None
+        db = K.colsum_bf16(dop)[:out_dim] if ctx.needs_input_grad[2] else None
+        return dx, dW, db
 
 
 class MaskedRows:

@@ -224,7 +224,7 @@ class GETRegionFinetune(BaseGETModel):
         x = self.region_embed(region_motif)
         x = Fn.concat_cls(x, self.cls_token)            # model/model.py:571-573
         x, _ = self.encoder(x)
-        return self.head_exp(x)          # drops CLS, Linear, Softplus (fused)
+        return self.head_exp(x, fused_softplus=True)          # drops CLS, Linear, Softplus (one kernel)
 
     def before_loss(self, output, batch):
         return {"exp": output}, {"exp": batch["exp_label"]}
@@ -254,7 +254,7 @@ class GETRegionFinetuneATAC(BaseGETModel):
         x = self.region_embed(region_motif)
         x = Fn.concat_cls(x, self.cls_token)            # model/model.py:571-573
         x, _ = self.encoder(x)
-        return self.head_exp(x)
+        return self.head_exp(x, fused_softplus=True)
 
     def before_loss(self, output, batch):
         return {"atpm": output}, {"atpm": batch["region_motif"][:, :, -1].unsqueeze(-1)}

@@ -72,8 +72,13 @@ class RegionEmbed(BaseModule):
 class ExpressionHead(BaseModule):
     """reference: model/modules.py:239-258 (`nn.Linear(embed_dim, output_dim)` named `head`).
 
-    `forward(tokens, softplus=True)` consumes the encoder's bf16 token tensor [B,N+1,D] (CLS first), drops the
-    CLS row, applies the Linear and the Softplus of model/model.py:575-576 in one kernel.
+    `forward(x)` keeps the reference's contract: x[B,N,D] (any float dtype, on the GPU) -> logits [B,N,output_dim],
+    no CLS handling, no Softplus (functional.HeadLinear; the same GEMM kernels, off the training path).
+    The region models call `forward(tokens, fused_softplus=True)` instead: `tokens` is the encoder's bf16 tensor
+    [B,N+1,D] (CLS first); one kernel drops the CLS row, applies the Linear and the Softplus of model/model.py:575-576
+    and returns [B,N,output_dim].  That form refuses anything but the encoder's own output, so a caller who slices the
+    CLS row off first (as model/model.py:575 does) gets an error instead of silently losing region 0.
+    (A forward hook on `head_exp` therefore sees softplus'ed predictions where the reference's sees logits.)
     """
 
     def __init__(self, cfg):
@@ -87,9 +92,13 @@ class ExpressionHead(BaseModule):
         self.head.weight.data.mul_(0.001)
         self.head.bias.data.mul_(0.001)
 
-    def forward(self, x, atac=None, softplus=True):
+    def forward(self, x, atac=None, fused_softplus=False):
         if atac is not None:
             raise NotImplementedError("atac input to ExpressionHead is not supported on the region hot path")
-        if not softplus:
-            raise NotImplementedError("ExpressionHead without the fused Softplus is not implemented")
+        if not fused_softplus:
+            return Fn.HeadLinear.apply(x, self.head.weight, self.head.bias)
+        if not getattr(x, "_getmi_encoder_tokens", False) or x.dtype != torch.bfloat16 or x.dim() != 3:
+            raise RuntimeError("ExpressionHead(fused_softplus=True) takes the encoder's own output (bf16 [B,N+1,D], CLS "
+                               "row included); for any other tensor call head(x) -- the reference's [B,N,D] -> logits "
+                               "contract -- and apply Softplus yourself")
         return Fn.ExpressionHeadSoftplus.apply(x, self.head.weight, self.head.bias)

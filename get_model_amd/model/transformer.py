@@ -39,6 +39,23 @@ class DropPath(nn.Module):
         return f"drop_prob={self.drop_prob:.3f}"
 
 
+def _refuse_forward_hook(self, *args, **kwargs):
+    """`Attention` / `Mlp` (and the `nn.Linear`s inside them) are parameter containers here: their forward never runs,
+    so a forward hook on them -- any module name is legal in the reference's interpretation config, run.py:359-384 --
+    would silently capture nothing.  Refused with a pointer to the modules whose outputs do exist."""
+    raise RuntimeError(f"get_model_amd: a forward hook on {type(self).__name__} would never fire -- attention and MLP "
+                       "run fused inside Block.forward (functional.EncoderBlock).  Hook `encoder.blocks.<i>` (the "
+                       "block's output), `region_embed` or `encoder` instead.")
+
+
+class _FusedLinear(nn.Linear):
+    """nn.Linear whose arithmetic runs inside the fused block kernels: a genuine nn.Linear for state_dict / LoRA
+    parametrisations (run_region.py:319-331), but forward hooks are refused (they would never fire)."""
+
+    register_forward_hook = _refuse_forward_hook
+    register_forward_pre_hook = _refuse_forward_hook
+
+
 class Attention(nn.Module):
     """Parameters of model/transformer.py:15-44 (packed qkv without bias + separate q_bias / v_bias)."""
 
@@ -54,16 +71,19 @@ class Attention(nn.Module):
         if attn_drop or proj_drop:
             raise NotImplementedError("attention / projection dropout > 0 is not on the region hot path "
                                       "(drop_rate and attn_drop_rate are 0 in every GETRegion* YAML)")
-        self.qkv = nn.Linear(dim, all_head_dim * 3, bias=False)
+        self.qkv = _FusedLinear(dim, all_head_dim * 3, bias=False)
         if qkv_bias:
             self.q_bias = nn.Parameter(torch.zeros(all_head_dim))
             self.v_bias = nn.Parameter(torch.zeros(all_head_dim))
         else:
             raise NotImplementedError("qkv_bias=False is not used by GETTransformer (default True)")
-        self.proj = nn.Linear(all_head_dim, dim)
+        self.proj = _FusedLinear(all_head_dim, dim)
 
     def forward(self, x, attention_mask=None, attention_bias=None):
         raise NotImplementedError("Attention runs fused inside Block.forward (functional.EncoderBlock)")
+
+    register_forward_hook = _refuse_forward_hook
+    register_forward_pre_hook = _refuse_forward_hook
 
 
 class Mlp(nn.Module):
@@ -75,12 +95,15 @@ class Mlp(nn.Module):
         hidden_features = hidden_features or in_features
         if act_layer is not nn.GELU or drop:
             raise NotImplementedError("the fused MLP kernel implements exact GELU without dropout")
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = _FusedLinear(in_features, hidden_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = _FusedLinear(hidden_features, out_features)
 
     def forward(self, x):
         raise NotImplementedError("Mlp runs fused inside Block.forward (functional.EncoderBlock)")
+
+    register_forward_hook = _refuse_forward_hook
+    register_forward_pre_hook = _refuse_forward_hook
 
 
 class Block(nn.Module):
@@ -178,4 +201,5 @@ class GETTransformer(nn.Module):
             prev = blk
         x = Fn.FinalNorm.apply(x, self.norm.weight, self.norm.bias, self.norm.eps, prev is not None,
                                None if prev is None else prev.last_scale2)
+        x._getmi_encoder_tokens = True      # what ExpressionHead(fused_softplus=True) insists on
         return x, None

@@ -201,10 +201,12 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         cache = Fn.WEIGHTS
-        cache.epoch += 1            # every cached copy is stale from here on, except the ones re-tagged below
         entries, sig = [], []
         table = {}      # (param group, step count) -> row of the hyper-parameter table: bias correction is per parameter
         retag = []      # in torch.optim.AdamW, so parameters of one group whose step counts differ get rows of their own
+        stepped = []
+        # pass 1 validates and collects WITHOUT touching any state: a raise below leaves every step count (and with it
+        # the bias correction of a retried step) as it was
         for gi, grp in enumerate(self.param_groups):
             for p in grp["params"]:
                 if p.grad is None:
@@ -213,24 +215,30 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW runs on the GPU only (no CPU fallback)")
                 if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("FusedAdamW needs dense contiguous fp32 parameters and gradients")
-                st = self._state(p)
-                st["step"] += 1
-                ti = table.setdefault((gi, float(st["step"])), len(table))
-                wn = cache.peek(p, "n")
-                wt = cache.peek(p, "t")
-                if wt is not None and not (p.ndim == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0):
-                    wt = None
-                entries.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], wn, wt, ti))
-                # every pointer the job table holds is part of the signature: load_state_dict() replaces the moment
-                # tensors while parameter and gradient addresses stay put
-                sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                            0 if wn is None else wn.data_ptr(), 0 if wt is None else wt.data_ptr(), ti))
-                if wn is not None:
-                    retag.append((p, "n"))
-                if wt is not None:
-                    retag.append((p, "t"))
+                st = self.state[p]
+                t_next = (float(st["step"]) if len(st) else 0.0) + 1.0
+                table.setdefault((gi, t_next), len(table))
+                stepped.append((gi, p, t_next))
         if len(table) > 64:
             raise RuntimeError("FusedAdamW: more than 64 (parameter group, step count) combinations")
+        cache.epoch += 1            # every cached copy is stale from here on, except the ones re-tagged below
+        for gi, p, t_next in stepped:
+            st = self._state(p)
+            st["step"] += 1
+            ti = table[(gi, t_next)]
+            wn = cache.peek(p, "n")
+            wt = cache.peek(p, "t")
+            if wt is not None and not (p.ndim == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0):
+                wt = None
+            entries.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], wn, wt, ti))
+            # every pointer the job table holds is part of the signature: load_state_dict() replaces the moment
+            # tensors while parameter and gradient addresses stay put
+            sig.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                        0 if wn is None else wn.data_ptr(), 0 if wt is None else wt.data_ptr(), ti))
+            if wn is not None:
+                retag.append((p, "n"))
+            if wt is not None:
+                retag.append((p, "t"))
         groups = (_Group * max(len(table), 1))()
         for (gi, t), ti in table.items():
             grp = self.param_groups[gi]

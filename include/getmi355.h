@@ -125,7 +125,11 @@ int getmi_scale_cast(const float* dx, const float* rowscale, int rows_per_sample
  * column-sum partials live in a 3 MiB device buffer built into the library (one copy per GPU, held until the process
  * ends).  Calls no hipMalloc / hipFree or other allocating routine.  Shapes whose getmi_scale_cast_workspace_bytes(M, D)
  * exceeds getmi_scale_cast_noalloc_max_bytes() are rejected (e.g. D = 1024 with M > 3072).  Every call on a GPU
- * shares that GPU's buffer: calls that overlap on one GPU (two streams, two threads) race. */
+ * shares that GPU's buffer: calls that overlap on one GPU (two streams, two threads) race.
+ * Set-up, once per device and OUTSIDE any stream capture: getmi_scale_cast_noalloc_max_bytes() (with that device
+ * current) or one eager getmi_scale_cast_noalloc call -- the first of them on a device looks up the buffer's address
+ * (hipGetSymbolAddress: may load the code object, not a capturable operation).  Every later call is two kernel
+ * launches and nothing else, and may be captured. */
 size_t getmi_scale_cast_noalloc_max_bytes(void);
 int getmi_scale_cast_noalloc(const float* dx, const float* rowscale, int rows_per_sample, void* dz_bf16, float* dbias,
                              int accumulate, int M, int D, void* stream);

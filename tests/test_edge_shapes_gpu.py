@@ -43,12 +43,18 @@ def test_edge_shape_matches_oracle(kind, B, N):
     assert perr <= 2.5e-2, f"pred err {perr}"
     assert abs(loss.item() - oloss.item()) <= 1e-2 * abs(oloss.item()) + 1e-5, (loss.item(), oloss.item())
     gg, og = grouped(grads), grouped({k: v for k, v in ograds.items() if k in grads})
+    worst = 1.0
     for n, g in gg.items():
         ref = og[n]
         if float(ref.abs().max()) < 1e-12:
             continue
         cos = F.cosine_similarity(g.flatten().float().cpu(), ref.flatten(), dim=0).item()
-        # tensors whose gradient is a pure cancellation sum at tiny T (q_bias with one or two keys) have no direction
-        if cos < 0.995 and float(ref.norm()) < 1e-6 * float(og[max(og, key=lambda k: float(og[k].norm()))].norm()):
+        # a gradient that is a pure cancellation sum at tiny T (q_bias with one key: softmax over one element has a zero
+        # Jacobian) has no direction: there both sides must be ZERO on the scale of the model's gradients
+        biggest = float(og[max(og, key=lambda k: float(og[k].norm()))].norm())
+        if float(ref.norm()) < 1e-6 * biggest:
+            assert float(g.float().cpu().norm()) <= 1e-5 * biggest, f"{n}: |g| {float(g.norm()):.3e} where the oracle has ~0"
             continue
-        assert cos >= 0.995, f"{n}: cosine {cos} (|ref| {float(ref.norm()):.3e})"
+        worst = min(worst, cos)
+        assert cos >= 0.998, f"{n}: cosine {cos} (|ref| {float(ref.norm()):.3e})"
+    print(f"MEASURED edge shape {kind} B={B} N={N}: pred err {perr:.2e}, min cosine {worst:.5f}")

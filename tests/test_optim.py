@@ -58,7 +58,49 @@ def test_parameter_groups_follow_the_reference_rules():
         for p in model.parameters():
             p.grad = torch.zeros_like(p)
         opt.step()
+    # a step that raises must not have advanced any step count (bias correction of the retry)
+    assert all(len(opt.state[p]) == 0 or float(opt.state[p]["step"]) == 0.0 for p in model.parameters())
     del sched
+
+
+@pytest.mark.parametrize("fixture", ["optim_groups_finetune_L12", "optim_groups_pretrain_L12", "optim_groups_atac_L3",
+                                     "optim_groups_finetune_L2_frozen"])
+def test_parameter_groups_equal_the_reference_optimizer(fixture):
+    """Pinned by the reference itself: oracle/make_golden_optim.py imported /root/reference/get_model/optim.py
+    (optim.py:16-144) and ran its `create_optimizer` the way run.py:477-497 does; this compares parameter by parameter
+    the group index (= order of the groups in the optimizer), weight_decay, the stored lr_scale, lr and the layer id."""
+    import json
+    import os
+    z = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_extra", fixture + ".json")))
+    model = build_model(region_model_yaml(z["kind"], num_layers=z["num_layers"]))
+    if z["frozen"]:
+        model.freeze_layers(patterns_to_freeze=z["frozen"], invert_match=False)
+    cfg = SimpleNamespace(opt="adamw", lr=1e-4, weight_decay=0.05, opt_eps=1e-8, opt_betas=[0.9, 0.999])
+    opt = O.configure_optimizer(model, cfg)
+    assert len(opt.param_groups) == z["n_groups"]
+    assert z["optimizer_class"] == "AdamW" and isinstance(opt, O.FusedAdamW)      # AdamW semantics, fused launch
+    for k, v in z["defaults"].items():
+        got = opt.defaults[k]
+        assert (list(got) if isinstance(got, (list, tuple)) else got) == v, k
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    seen = {}
+    for gi, g in enumerate(opt.param_groups):
+        for p in g["params"]:
+            seen[name_of[id(p)]] = [gi, float(g["weight_decay"]), float(g["lr_scale"]), float(g["lr"])]
+    assert set(seen) == set(z["params"])
+    for n, want in z["params"].items():
+        assert seen[n][0] == want[0] and seen[n][1] == want[1], (n, seen[n], want)
+        assert seen[n][2] == pytest.approx(want[2], rel=1e-12) and seen[n][3] == pytest.approx(want[3]), (n, seen[n], want)
+        assert O.get_num_layer_for_vit(n, z["num_layers"] + 2) == z["layer_ids"][n], n
+    # within each group the parameters come in the reference's order (named_parameters order)
+    ref_order = {}
+    for n, want in z["params"].items():
+        ref_order.setdefault(want[0], []).append(n)
+    got_order = {}
+    for n, v in seen.items():
+        got_order.setdefault(v[0], []).append(n)
+    for gi in got_order:
+        assert sorted(got_order[gi]) == sorted(ref_order[gi])
 
 
 @pytest.mark.gpu

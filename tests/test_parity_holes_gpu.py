@@ -171,12 +171,14 @@ def test_c4_long_context_atac_slice_against_the_oracle():
         p2, ob2 = model.before_loss(o2, sb)
         l2 = model.after_loss(model.loss(p2, ob2)) * (len(sel) / B)
         l2.backward()
+    worst = (1.0, "")
     for n, p in model.named_parameters():
-        if n.endswith("attn.q_bias"):
-            continue      # a cancellation sum: compared on its own scale in test_model_parity_gpu.py
         ref = g_full[n].float().flatten()
         cos = F.cosine_similarity(p.grad.float().flatten(), ref, dim=0).item()
-        assert cos > 0.999, (n, cos)
+        worst = min(worst, (cos, n))
+        # q_bias is a cancellation sum (rows of the softmax Jacobian sum to zero): same test, its own bar
+        assert cos > (0.99 if n.endswith("attn.q_bias") else 0.999), (n, cos)
+    print(f"MEASURED C4 linearity: min cosine {worst[0]:.6f} ({worst[1]})")
 
 
 def _close(name, got, idx, vals, gsum, tol_val=6e-2, tol_norm=4e-2):

@@ -1,0 +1,454 @@
+"""GPU: parity holes VERDICT r2 listed (all against the oracle / the reference-made fixtures, through the C ABI):
+
+  * the product's own stochastic-depth draw (`GETTransformer._draw_drop_path`, the train-mode step bench.py times):
+    its statistics, and a train-mode step whose drawn factors are captured and fed to the oracle as keep masks
+    (model/transformer.py:220,247-248,323-325);
+  * BASELINE configs[1] shape (B=256 x N=200: persistent GEMMs, 224-row tiles, split wgrad slabs, streamed attention
+    backward): EVERY parameter gradient against the oracle at L=2, and at L=12 d loss / d region_motif of four samples;
+  * LoRA through torch.nn.utils.parametrize on attn.qkv / attn.proj / mlp.fc1 / mlp.fc2 (run_region.py:319-352);
+  * the three shipped checkpoint maps loaded through checkpoint.load_finetune_checkpoint -> .cuda() -> prediction
+    (utils.py:147-227, config/finetune/{lightning,v1_finetune,v1_pretrain}.yaml);
+  * fp16 autocast + GradScaler, the reference's dataclass default (config/config.py:238, utils.py:100-102);
+  * boundary that fails loudly: ExpressionHead's reference contract, refused forward hooks, ConcatCLS ownership.
+Every test prints the values it measured ("MEASURED ..."); the bars are about twice the worst value seen on MI355X.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import get_cpu as O
+from tests.golden_util import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _model(kind, L, sd, train=False):
+    from get_model_amd.config import build_model, region_model_yaml
+    m = build_model(region_model_yaml(kind, num_layers=L))
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train(train)
+
+
+def _step(m, batch):
+    out = m(**m.get_input(batch))
+    pred, obs = m.before_loss(out, batch)
+    return m.after_loss(m.loss(pred, obs)), pred[list(pred)[0]]
+
+
+def _grad_errors(grads, ograds):
+    """{name: (normalised max-abs error over the FULL tensor, |norm ratio - 1|, cosine)} vs the oracle."""
+    out = {}
+    for n, og in ograds.items():
+        g = grads[n].detach().float().cpu()
+        scale = max(og.abs().max().item(), og.norm().item() / og.numel() ** 0.5, 1e-20)
+        err = (g - og).abs().max().item() / scale
+        nr = abs(g.norm().item() / max(og.norm().item(), 1e-20) - 1)
+        cos = F.cosine_similarity(g.flatten(), og.flatten(), dim=0).item()
+        out[n] = (err, nr, cos)
+    return out
+
+
+def _report(tag, errs):
+    worst_e = max(errs.items(), key=lambda kv: kv[1][0])
+    worst_n = max(errs.items(), key=lambda kv: kv[1][1])
+    worst_c = min(errs.items(), key=lambda kv: kv[1][2])
+    print(f"MEASURED {tag}: worst max-abs {worst_e[1][0]:.3e} ({worst_e[0]}), worst norm dev {worst_n[1][1]:.3e} "
+          f"({worst_n[0]}), min cosine {worst_c[1][2]:.6f} ({worst_c[0]})")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_drop_path_draw_statistics():
+    """`_draw_drop_path`: block 0 (rate 0) is the identity, every other factor is 0 or 1/keep_i exactly, the mean
+    over 4096 samples is 1 within 5 sigma, the two draws of a block and two calls are independent."""
+    _need_gpu()
+    from get_model_amd.config import build_model, region_model_yaml
+    m = build_model(region_model_yaml("finetune", num_layers=12)).cuda()
+    enc = m.encoder
+    enc.eval()
+    assert enc._draw_drop_path(8, "cuda") is None
+    enc.train()
+    B = 4096
+    torch.manual_seed(11)
+    f = enc._draw_drop_path(B, torch.device("cuda"))
+    g = enc._draw_drop_path(B, torch.device("cuda"))
+    rates = O.drop_path_rates(12, 0.1)
+    assert len(f) == 12 and f[0] is None and g[0] is None
+    worst_sigma = 0.0
+    for i in range(1, 12):
+        keep = 1.0 - rates[i]
+        assert abs(enc.blocks[i].drop_path.drop_prob - rates[i]) < 1e-7
+        for t in (f[i][0], f[i][1], g[i][0], g[i][1]):
+            assert t.shape == (B,) and t.dtype == torch.float32 and t.is_contiguous()
+            vals = torch.unique(t).cpu()
+            assert all(v == 0.0 or abs(v - 1.0 / keep) <= 1e-6 / keep for v in vals.tolist()), (i, vals)
+            sigma = ((1 - keep) / keep / B) ** 0.5
+            dev = abs(t.mean().item() - 1.0) / sigma
+            worst_sigma = max(worst_sigma, dev)
+            assert dev < 5.0, (i, t.mean().item())
+        # independent draws: the two branches of a block and two forwards do not share their masks
+        for a, b in ((f[i][0], f[i][1]), (f[i][0], g[i][0]), (f[i][1], g[i][1])):
+            agree = ((a > 0) == (b > 0)).float().mean().item()
+            expect = keep * keep + (1 - keep) * (1 - keep)
+            assert abs(agree - expect) < 0.03 and not torch.equal(a, b), (i, agree, expect)
+    # different layers do not share their masks either
+    assert not torch.equal(f[5][0] > 0, f[6][0] > 0)
+    print(f"MEASURED drop_path draw: worst |mean-1| = {worst_sigma:.2f} sigma over 44 draws of {B}")
+
+
+def test_train_step_with_the_products_own_drop_path_draw_matches_the_oracle():
+    """One train-mode step with NO injected masks: the factors `_draw_drop_path` produced are captured on the way
+    and handed to the oracle as keep masks; loss, prediction and every gradient must agree."""
+    _need_gpu()
+    L, B, N = 6, 24, 50
+    sd = O.fill_state_dict("finetune", seed=41, num_layers=L)
+    m = _model("finetune", L, sd, train=True)
+    enc = m.encoder
+    captured = {}
+    orig = enc._draw_drop_path
+
+    def spy(batch, device):
+        f = orig(batch, device)
+        captured["f"] = f
+        return f
+
+    enc._draw_drop_path = spy
+    torch.manual_seed(5)
+    batch = O.make_batch(B, N, 91)
+    loss, pred = _step(m, {k: v.cuda() for k, v in batch.items()})
+    loss.backward()
+    f = captured["f"]
+    assert f is not None and f[0] is None and all(x is not None for x in f[1:])
+    keep = [None if x is None else ((x[0] > 0).float().cpu(), (x[1] > 0).float().cpu()) for x in f]
+    dropped = sum(int((1 - k[0]).sum() + (1 - k[1]).sum()) for k in keep if k is not None)
+    assert dropped > 0, "the draw dropped nothing: the test would not exercise stochastic depth"
+    torch.set_num_threads(16)
+    oloss, opred, og = O.loss_and_grads("finetune", sd, batch, num_layers=L, keep_masks=keep)
+    perr = (pred.detach().float().cpu() - opred).abs().max().item() / opred.abs().max().item()
+    lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    errs = _grad_errors({n: p.grad for n, p in m.named_parameters()}, og)
+    print(f"MEASURED own-draw train step: {dropped} branch drops, pred err {perr:.2e}, loss err {lerr:.2e}")
+    _report("own-draw train step grads", errs)
+    assert perr <= 1.5e-2 and lerr <= 4e-3
+    for n, (e, nr, cos) in errs.items():
+        assert e <= 6e-2 and nr <= 3e-2 and cos >= 0.998, (n, e, nr, cos)
+
+
+def test_c2_shape_every_gradient_against_the_oracle():
+    """BASELINE configs[1] shape, B=256 x N=200 (M = 51 456 rows), 2 layers: the oracle runs the same batch on the host
+    (about 5 s); every parameter gradient is compared over the FULL tensor."""
+    _need_gpu()
+    L, B, N = 2, 256, 200
+    sd = O.fill_state_dict("finetune", seed=43, num_layers=L)
+    m = _model("finetune", L, sd)
+    batch = O.make_batch(B, N, 93)
+    loss, pred = _step(m, {k: v.cuda() for k, v in batch.items()})
+    loss.backward()
+    torch.set_num_threads(16)
+    oloss, opred, og = O.loss_and_grads("finetune", sd, batch, num_layers=L)
+    perr = (pred.detach().float().cpu() - opred).abs().max().item() / opred.abs().max().item()
+    lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    errs = _grad_errors({n: p.grad for n, p in m.named_parameters()}, og)
+    print(f"MEASURED C2 shape L=2: pred err {perr:.2e}, loss err {lerr:.2e}")
+    _report("C2 shape L=2 grads", errs)
+    for n, (e, nr, cos) in sorted(errs.items(), key=lambda kv: -kv[1][0])[:5]:
+        print(f"MEASURED   {n}: max-abs {e:.3e} norm dev {nr:.3e} cos {cos:.6f}")
+    assert perr <= 1.5e-2 and lerr <= 2e-3
+    for n, (e, nr, cos) in errs.items():
+        assert e <= 5e-2 and nr <= 2e-2 and cos >= 0.999, (n, e, nr, cos)
+
+
+def test_c2_shape_twelve_layers_input_gradient_of_four_samples():
+    """BASELINE configs[1] at full depth (12 layers, B=256 x N=200, eval-mode arithmetic): d loss / d region_motif of
+    four samples against the oracle run on those samples alone.  The loss is a mean over the batch and samples are
+    independent on this path, so the full-batch gradient of sample b is 4/B of the gradient in the 4-sample batch.  The
+    backward of all 12 layers at M = 51 456 rows is on the way to this tensor."""
+    _need_gpu()
+    L, B, N = 12, 256, 200
+    sd = O.fill_state_dict("finetune", seed=44, num_layers=L)
+    m = _model("finetune", L, sd)
+    batch = O.make_batch(B, N, 94)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    x = cb["region_motif"].requires_grad_(True)
+    loss, pred = _step(m, cb)
+    loss.backward()
+    idx = [0, 77, 200, 255]
+    torch.set_num_threads(16)
+    leaf = batch["region_motif"][idx].clone().requires_grad_(True)
+    ol, opred = O.finetune_loss(sd, {"region_motif": leaf, "exp_label": batch["exp_label"][idx]}, num_layers=L)
+    ol.backward()
+    got = x.grad[idx].float().cpu() * (B / len(idx))
+    ref = leaf.grad
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    cos = F.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+    nr = abs(got.norm().item() / ref.norm().item() - 1)
+    perr = (pred[idx].detach().float().cpu() - opred).abs().max().item() / opred.abs().max().item()
+    print(f"MEASURED C2 shape L=12 d loss/d region_motif (4 samples): max-abs {err:.3e}, norm dev {nr:.3e}, "
+          f"cosine {cos:.6f}; pred err {perr:.2e}")
+    assert err <= 6e-2 and nr <= 2e-2 and cos >= 0.998 and perr <= 2e-2
+    # and the weight gradients at this depth and size stay finite and non-trivial
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0, n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class _LoRA(torch.nn.Module):
+    """W + B @ A * (alpha / r): what minlora's LoRAParametrization.from_linear builds (run_region.py:319-324, rank 8)."""
+
+    def __init__(self, fan_out, fan_in, rank=8, alpha=8.0, seed=0):
+        super().__init__()
+        self.lora_A = torch.nn.Parameter(O.hash_tensor((rank, fan_in), 600 + seed, -0.05, 0.05))
+        self.lora_B = torch.nn.Parameter(O.hash_tensor((fan_out, rank), 700 + seed, -0.05, 0.05))
+        self.scaling = alpha / rank
+
+    def forward(self, W):
+        return W + (self.lora_B @ self.lora_A) * self.scaling
+
+
+def test_lora_parametrised_linear_weights_train_through_the_fused_block():
+    """torch.nn.utils.parametrize on the four Linear weights of every block, base weights frozen: the fused block reads
+    `linear.weight` at call time like the reference (model/transformer.py:57), so loss and LoRA-factor gradients must
+    equal the oracle's on the merged weights, chained through dW -> (dB, dA)."""
+    _need_gpu()
+    import torch.nn.utils.parametrize as P
+    L, B, N = 2, 4, 60
+    sd = O.fill_state_dict("finetune", seed=45, num_layers=L)
+    m = _model("finetune", L, sd)
+    names = ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+    lora = {}
+    for i, blk in enumerate(m.encoder.blocks):
+        for j, nm in enumerate(names):
+            lin = blk.get_submodule(nm)
+            assert isinstance(lin, torch.nn.Linear)
+            par = _LoRA(lin.out_features, lin.in_features, seed=10 * i + j).cuda()
+            P.register_parametrization(lin, "weight", par)
+            lora[f"encoder.blocks.{i}.{nm}"] = par
+    for n, p in m.named_parameters():            # what freeze_layers / minlora leave trainable: the LoRA factors
+        p.requires_grad = "lora_" in n
+    assert not isinstance(m.encoder.blocks[0].attn.qkv.weight, torch.nn.Parameter)
+    batch = O.make_batch(B, N, 95)
+    loss, pred = _step(m, {k: v.cuda() for k, v in batch.items()})
+    loss.backward()
+    merged = dict(sd)
+    for key, par in lora.items():
+        merged[key + ".weight"] = par(sd[key + ".weight"].cuda()).detach().cpu()
+    torch.set_num_threads(16)
+    oloss, opred, og = O.loss_and_grads("finetune", merged, batch, num_layers=L)
+    lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    perr = (pred.detach().float().cpu() - opred).abs().max().item() / opred.abs().max().item()
+    errs = {}
+    want = {}
+    for key, par in lora.items():
+        dW = og[key + ".weight"]
+        want[key + ".lora_B"] = (dW @ par.lora_A.detach().cpu().t()) * par.scaling
+        want[key + ".lora_A"] = (par.lora_B.detach().cpu().t() @ dW) * par.scaling
+    got = {key + ".lora_B": par.lora_B.grad for key, par in lora.items()}
+    got.update({key + ".lora_A": par.lora_A.grad for key, par in lora.items()})
+    assert all(g is not None for g in got.values())
+    errs = _grad_errors(got, want)
+    print(f"MEASURED LoRA: loss err {lerr:.2e}, pred err {perr:.2e}")
+    _report("LoRA factor grads", errs)
+    assert lerr <= 4e-3 and perr <= 1.5e-2
+    for n, (e, nr, cos) in errs.items():
+        assert e <= 5e-2 and nr <= 3e-2 and cos >= 0.998, (n, e, nr, cos)
+    # frozen base weights and everything else got no gradient
+    for n, p in m.named_parameters():
+        if "lora_" not in n:
+            assert p.grad is None, n
+    # state_dict keeps the base weight under parametrize's `original` name (what minlora checkpoints hold)
+    assert "encoder.blocks.0.attn.qkv.parametrizations.weight.original" in m.state_dict()
+
+
+def test_shipped_checkpoint_maps_load_and_predict_on_the_gpu(tmp_path):
+    """config/finetune/{lightning,v1_finetune,v1_pretrain}.yaml through checkpoint.load_finetune_checkpoint, then
+    .cuda() and a forward against the oracle run on the weights that were written to the file."""
+    _need_gpu()
+    from get_model_amd import checkpoint as C
+    from get_model_amd.config import build_model, region_model_yaml
+    L, B, N = 2, 3, 40
+    torch.set_num_threads(16)
+
+    def legacy_names(sd, pairs):
+        out = {}
+        for k, v in sd.items():
+            for a, b in pairs:
+                k = k.replace(a, b)
+            out[k] = v.clone()
+        return out
+
+    cases = []
+    sd_ft = O.fill_state_dict("finetune", seed=46, num_layers=L)
+    sd_pre = O.fill_state_dict("pretrain", seed=47, num_layers=L)
+    # (kind, file content, finetune cfg, weights the forward must reflect)
+    cases.append(("finetune", {"state_dict": {"model." + k: v for k, v in sd_ft.items()}},
+                  {"model_key": "state_dict", "rename_config": C.RENAME_LIGHTNING, "patterns_to_drop": [], "strict": True}, sd_ft))
+    v1_ft = legacy_names(sd_ft, [("encoder.blocks.", "blocks."), ("encoder.norm.", "fc_norm."),
+                                 ("region_embed.embed.", "region_embed.proj."), ("head_exp.head.", "head."),
+                                 ("region_embed", "encoder.region_embed"), ("cls_token", "encoder.cls_token")])
+    assert "encoder.region_embed.proj.weight" in v1_ft and "encoder.cls_token" in v1_ft and "fc_norm.weight" in v1_ft
+    cases.append(("finetune", {"model": v1_ft}, {"model_key": "model", "rename_config": C.RENAME_V1_FINETUNE, "strict": True}, sd_ft))
+    v1_pre = legacy_names(sd_pre, [("head_mask.", "encoder.head."), ("region_embed.embed.", "region_embed.proj."),
+                                   ("region_embed", "encoder.region_embed"), ("cls_token", "encoder.cls_token")])
+    assert "encoder.head.weight" in v1_pre and "encoder.blocks.0.attn.qkv.weight" in v1_pre
+    cases.append(("pretrain", {"model": v1_pre}, {"model_key": "model", "rename_config": C.RENAME_V1_PRETRAIN, "strict": True}, sd_pre))
+    for ci, (kind, content, cfg, sd) in enumerate(cases):
+        path = str(tmp_path / f"ckpt{ci}.pth")
+        torch.save(content, path)
+        torch.manual_seed(ci)
+        m = build_model(region_model_yaml(kind, num_layers=L))
+        res = C.load_finetune_checkpoint(m, dict(cfg, checkpoint=path))
+        assert not res.missing_keys and not res.unexpected_keys, (ci, res)
+        m = m.cuda().eval()
+        batch = O.make_batch(B, N, 96 + ci, kind=kind)
+        with torch.no_grad():
+            loss, pred = _step(m, {k: v.cuda() for k, v in batch.items()})
+        if kind == "pretrain":
+            oloss, opred = O.pretrain_loss(sd, batch, num_layers=L)
+        else:
+            oloss, opred = O.finetune_loss(sd, batch, num_layers=L)
+        perr = (pred.float().cpu() - opred).abs().max().item() / opred.abs().max().item()
+        lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+        print(f"MEASURED checkpoint map {ci} ({kind}): pred err {perr:.2e}, loss err {lerr:.2e}")
+        assert perr <= 1.5e-2 and lerr <= 4e-3
+        # export -> import round trip on the GPU model (Lightning layout)
+        back = C.save_checkpoint(m, str(tmp_path / f"back{ci}.ckpt"))
+        m2 = build_model(region_model_yaml(kind, num_layers=L))
+        C.load_finetune_checkpoint(m2, {"checkpoint": back, "model_key": "state_dict", "rename_config": C.RENAME_LIGHTNING})
+        with torch.no_grad():
+            loss2, _ = _step(m2.cuda().eval(), {k: v.cuda() for k, v in batch.items()})
+        assert torch.equal(loss2, loss)
+
+
+def test_fp16_autocast_with_grad_scaler_two_steps_follow_the_oracle():
+    """The reference's default precision (config/config.py:238 use_fp16=True -> Lightning MixedPrecision("16-mixed"),
+    utils.py:100-102) = torch.autocast(float16) around the step + GradScaler: the loss is scaled by 2^16 before
+    backward, so every bf16 gradient stream of the fused backward carries values 65 536 x larger; unscale, AdamW step,
+    second step.  Against the oracle trained on the host in fp32 with torch.optim.AdamW."""
+    _need_gpu()
+    L, B, N = 2, 4, 50
+    sd = O.fill_state_dict("finetune", seed=48, num_layers=L)
+    m = _model("finetune", L, sd)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ropt = torch.optim.AdamW(list(ref.values()), lr=1e-3, weight_decay=0.05)
+    torch.set_num_threads(16)
+    for step in range(2):
+        batch = O.make_batch(B, N, 97 + step)
+        cb = {k: v.cuda() for k, v in batch.items()}
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, pred = _step(m, cb)
+        assert loss.dtype == torch.float32 and pred.dtype == torch.float32
+        scaler.scale(loss).backward()
+        big = m.encoder.blocks[0].mlp.fc1.weight.grad.abs().max().item()
+        scaler.unscale_(opt)
+        ropt.zero_grad(set_to_none=True)
+        oloss, _ = O.finetune_loss(ref, batch, num_layers=L)
+        oloss.backward()
+        errs = _grad_errors({n: p.grad for n, p in m.named_parameters()}, {k: v.grad for k, v in ref.items()})
+        lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+        print(f"MEASURED fp16-mixed step {step}: loss err {lerr:.2e}, scaled |dW| max {big:.3e}")
+        _report(f"fp16-mixed step {step} grads", errs)
+        assert lerr <= 5e-3
+        for n, (e, nr, cos) in errs.items():
+            assert e <= 6e-2 and nr <= 3e-2 and cos >= 0.998, (step, n, e, nr, cos)
+        scaler.step(opt)
+        scaler.update()
+        ropt.step()
+        assert scaler.get_scale() == 2.0 ** 16          # no overflow was found
+    # after two steps the weights moved the same way
+    for n, p in m.named_parameters():
+        d_got = p.detach().cpu() - sd[n]
+        d_ref = ref[n].detach() - sd[n]
+        if d_ref.norm().item() < 1e-9:
+            continue
+        cos = F.cosine_similarity(d_got.flatten(), d_ref.flatten(), dim=0).item()
+        assert cos >= 0.97, (n, cos)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_expression_head_keeps_the_reference_contract_and_fails_loudly():
+    """model/modules.py:255-258: `head_exp(x)` is a plain Linear on [B,N,D] returning logits.  The fused form is what
+    the models call; handing it CLS-dropped tokens must raise, not lose region 0."""
+    _need_gpu()
+    c = load_case("ft_L2_B2_N200_eval")
+    m = _model("finetune", 2, c["sd"])
+    W, b = c["sd"]["head_exp.head.weight"], c["sd"]["head_exp.head.bias"]
+    x = O.hash_tensor((2, 200, 768), 123, -2.0, 2.0)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        xd = x.cuda().to(dt).requires_grad_(True)
+        y = m.head_exp(xd)
+        ref_in = xd.detach().float().cpu().bfloat16().float().requires_grad_(True)
+        ref = F.linear(ref_in, W.bfloat16().float(), b)
+        assert y.shape == (2, 200, 2) and y.dtype == torch.float32
+        err = (y.detach().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= 2e-3, (dt, err)
+        w = O.hash_tensor((2, 200, 2), 124, -1.0, 1.0)
+        m.zero_grad(set_to_none=True)
+        (y * w.cuda()).sum().backward()
+        (ref * w).sum().backward()
+        assert xd.grad.dtype == dt and xd.grad.shape == xd.shape
+        gcos = F.cosine_similarity(xd.grad.float().cpu().flatten(), ref_in.grad.flatten(), dim=0).item()
+        dW = torch.einsum("bno,bnd->od", w, ref_in.detach())
+        wcos = F.cosine_similarity(m.head_exp.head.weight.grad.cpu().flatten(), dW.flatten(), dim=0).item()
+        bdev = (m.head_exp.head.bias.grad.cpu() - w.sum((0, 1))).abs().max().item()
+        assert gcos >= 0.9995 and wcos >= 0.9995 and bdev <= 0.05, (dt, gcos, wcos, bdev)
+    tokens, _ = m.encoder(Fn_concat(m, c))
+    with pytest.raises(RuntimeError, match="encoder's own output"):
+        m.head_exp(tokens[:, 1:], fused_softplus=True)          # the reference's call shape (model/model.py:575)
+    with pytest.raises(RuntimeError, match="encoder's own output"):
+        m.head_exp(tokens.float(), fused_softplus=True)
+    pred = m.head_exp(tokens, fused_softplus=True)
+    logits = m.head_exp(tokens[:, 1:])                          # reference contract on the same tokens
+    assert torch.allclose(F.softplus(logits), pred, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="no CPU fallback|only on an MI355X"):
+        m.head_exp(x)                                           # CPU tensor
+
+
+def Fn_concat(m, c):
+    from get_model_amd import functional as Fn
+    return Fn.concat_cls(m.region_embed(c["batch"]["region_motif"].cuda()), m.cls_token)
+
+
+def test_forward_hooks_that_could_never_fire_are_refused():
+    """run.py:359-384 hooks any module name the config lists.  `attn`, `mlp` and the Linears inside them run fused in
+    Block.forward, so a hook there would capture nothing: registering one raises and names the modules that work."""
+    _need_gpu()
+    c = load_case("ft_L2_B2_N200_eval")
+    m = _model("finetune", 2, c["sd"])
+    for name in ("encoder.blocks.0.attn", "encoder.blocks.1.mlp", "encoder.blocks.0.attn.qkv", "encoder.blocks.1.mlp.fc2"):
+        with pytest.raises(RuntimeError, match=r"encoder\.blocks\.<i>"):
+            m.get_submodule(name).register_forward_hook(lambda *a: None)
+        with pytest.raises(RuntimeError, match="never fire"):
+            m.get_submodule(name).register_forward_pre_hook(lambda *a: None)
+    seen = []
+    hooks = [m.get_submodule(n).register_forward_hook(lambda mod, i, o, n=n: seen.append(n))
+             for n in ("region_embed", "encoder.blocks.0", "encoder.blocks.1", "encoder", "head_exp")]
+    m(c["batch"]["region_motif"].cuda())
+    assert seen == ["region_embed", "encoder.blocks.0", "encoder.blocks.1", "encoder", "head_exp"]
+    for h in hooks:
+        h.remove()
+
+
+def test_second_concat_cls_on_one_embedding_does_not_overwrite_the_first():
+    """ConcatCLS fills row 0 behind region_embed's output in place; a second concat (two towers, another
+    cls_token) must copy instead of overwriting the CLS row under the first result."""
+    _need_gpu()
+    from get_model_amd import functional as Fn
+    c = load_case("atac_L2_B2_N37_eval")
+    m = _model("atac", 2, c["sd"])
+    e = m.region_embed(c["batch"]["region_motif"].cuda())
+    cls_a = torch.full((1, 1, 768), 3.0, device="cuda")
+    cls_b = torch.full((1, 1, 768), -5.0, device="cuda")
+    fa = Fn.concat_cls(e, cls_a)
+    fb = Fn.concat_cls(e, cls_b)
+    assert fa.data_ptr() != fb.data_ptr()
+    assert bool((fa[:, 0] == 3.0).all()) and bool((fb[:, 0] == -5.0).all())
+    assert torch.equal(fa[:, 1:], e) and torch.equal(fb[:, 1:], e)

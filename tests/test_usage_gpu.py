@@ -19,13 +19,22 @@ def mk(kind, L=2):
 def step(m, batch):
     out = m(**m.get_input(batch)); pred, obs = m.before_loss(out, batch); return m.after_loss(m.loss(pred, obs)), pred
 
+
 def p_mask_all(value):
     def f():
         m, sd = mk("pretrain"); b = O.make_batch(2, 30, 1, kind="pretrain"); b["mask"][:] = value
         dev = {k: v.cuda() for k, v in b.items()}
-        loss, _ = step(m, dev)
+        loss, pred = step(m, dev)
         if value == 0:
-            return True if (torch.isnan(loss) or float(loss.detach()) == 0.0 or torch.isfinite(loss)) else "loss"
+            # the reference's mean-reduced MSELoss over no rows is NaN (model/model.py:527-536 with an all-zero mask);
+            # the output has no rows, backward runs without raising and leaves zero (or no) gradients
+            if not torch.isnan(loss):
+                return f"loss over no rows is {float(loss.detach())}, expected NaN"
+            if tuple(pred["masked"].shape) != (0, 283):
+                return f"output shape {tuple(pred['masked'].shape)}"
+            loss.backward()
+            bad = [n for n, p in m.named_parameters() if p.grad is not None and bool((p.grad != 0).any())]
+            return True if not bad else "non-zero gradients from an empty loss: " + str(bad[:4])
         loss.backward(); ol, _, _ = O.loss_and_grads("pretrain", sd, b, num_layers=2, drop_path_rate=0.0)
         return abs(float(loss.detach()) - float(ol)) <= 1e-2 * abs(float(ol)) or f"{float(loss.detach())} vs {float(ol)}"
     return f
@@ -36,14 +45,15 @@ def p_two_forwards_one_backward():
     (step(m, d1)[0] + step(m, d2)[0]).backward()
     _, _, g1 = O.loss_and_grads("finetune", sd, b1, num_layers=2, drop_path_rate=0.0)
     _, _, g2 = O.loss_and_grads("finetune", sd, b2, num_layers=2, drop_path_rate=0.0)
-    bad = []
+    bad = []; worst = 1.0
     for n, p in m.named_parameters():
         ref = g1[n] + g2[n]
         if float(ref.norm()) < 1e-9: continue
         cos = torch.nn.functional.cosine_similarity(p.grad.flatten().cpu(), ref.flatten(), dim=0).item()
         rel = float(p.grad.cpu().norm() / ref.norm())
-        if n.endswith("q_bias"): continue
-        if cos < 0.99 or abs(rel - 1) > 0.05: bad.append((n, round(cos, 4), round(rel, 3)))
+        worst = min(worst, cos)
+        if cos < 0.998 or abs(rel - 1) > 0.03: bad.append((n, round(cos, 4), round(rel, 3)))
+    print(f"MEASURED two_forwards_one_backward: min cosine {worst:.5f}")
     return True if not bad else str(bad[:4])
 
 def p_accumulate_two_backwards():
@@ -93,8 +103,9 @@ def test_usage(probe):
 
 
 def test_autocast_context_changes_nothing():
-    """The reference trains under bf16 autocast (Lightning precision); the fused path already computes in bf16 with fp32
-    accumulation and must give the same loss and gradients inside the context."""
+    """A torch.autocast context around the step (the reference's own mixed-precision mode is fp16 autocast + GradScaler,
+    utils.py:100-102: tests/test_round3_gpu.py; bf16 here is what a user of this build would pick) must change nothing:
+    the fused path computes in bf16 with fp32 accumulation whatever the context says."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     m, sd = mk("finetune")
@@ -137,11 +148,11 @@ def test_torch_ddp_wrapper_on_rccl_world_of_one():
             pred, obs = m.before_loss(out, d)
             m.after_loss(m.loss(pred, obs)).backward()
             for n, p in m.named_parameters():
-                if float(og[n].norm()) < 1e-9 or n.endswith("q_bias"):
+                if float(og[n].norm()) < 1e-9:
                     continue
                 assert p.grad is not None, n
                 cos = F.cosine_similarity(p.grad.flatten().cpu(), og[n].flatten(), dim=0).item()
                 rel = float(p.grad.cpu().norm() / og[n].norm())
-                assert cos >= 0.99 and abs(rel - 1) <= 0.05, (it, n, cos, rel)
+                assert cos >= 0.998 and abs(rel - 1) <= 0.03, (it, n, cos, rel)
     finally:
         dist.destroy_process_group()

@@ -67,3 +67,36 @@ def test_noalloc_entry_point_rejects_what_does_not_fit():
     assert bool((dz == 7).all()) and bool((db == 7).all())       # nothing was launched
     with pytest.raises(RuntimeError, match="scratch"):
         L.call("getmi_scale_cast_noalloc", dx, None, 0, dz, db, 0, M, D)
+
+
+def test_noalloc_entry_point_inside_a_hip_graph_capture():
+    """the header names HIP graph capture as a caller.  After the per-device set-up query (outside capture)
+    a call made while a stream is capturing must enqueue only kernel nodes: captured once, replayed on new inputs,
+    bit-identical to the workspace entry point each time."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from get_model_amd import kernels as K
+    from get_model_amd import lib as L
+    lib = L.load()
+    assert lib.getmi_scale_cast_noalloc_max_bytes() == 3 << 20          # the set-up call: resolves the scratch address
+    B, T, D = 16, 201, 768
+    M = B * T
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dx = torch.randn(M, D, generator=g).cuda()
+    scale = (torch.rand(B, generator=g) < 0.8).float().div(0.8).cuda()
+    dz = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    dbias = torch.empty(D, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rc = lib.getmi_scale_cast_noalloc(dx.data_ptr(), scale.data_ptr(), T, dz.data_ptr(), dbias.data_ptr(), 0, M, D,
+                                          torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.getmi_last_error().decode()
+    for seed in (1, 2):
+        dx.copy_(torch.randn(M, D, generator=g))
+        dz.zero_()
+        dbias.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        dz_ref, db_ref = K.scale_cast(dx, scale, T)
+        assert torch.equal(dz, dz_ref) and torch.equal(dbias, db_ref), seed
