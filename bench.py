@@ -26,6 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E peak (same guide; 6.3 TB/s is what a streaming copy reaches)
 FLOP_PER_REGION_N200 = 5.358e8   # fwd+bwd algorithmic FLOPs per region at N=200 (SURVEY.md 8d / BASELINE.md 4)
 
 
@@ -81,27 +82,34 @@ _TRAFFIC_GROUPS = {
 }
 
 
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(group):
-    """HBM-side bytes per launch of a kernel group (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md corrections),
-    from the committed rocprofv3 --pmc passes of this same workload (tools/pmc_traffic.sh -> profiles/); PMC
-    counters cannot be read from inside the process, so this is None when the file or the group is missing."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"))
-                 if os.path.exists(q)), None)
+    """(bytes per launch, provenance) of a kernel group: HBM-side bytes (FETCH_SIZE x2 + WRITE_SIZE, the corrections of
+    MI355X_MICROARCH.md) from the committed rocprofv3 --pmc passes of this same workload (tools/pmc_traffic.sh ->
+    profiles/).  PMC counters cannot be read from inside the process, so this number is NOT measured in this run: the
+    provenance names the file and the commit / command it was taken at ("_meta" entry of the file).  (None, None) when the
+    file or the group is missing."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f) for f in PMC_FILES) if os.path.exists(q)), None)
     if group not in _TRAFFIC_GROUPS or path is None:
-        return None
+        return None, None
     with open(path) as f:
         d = json.load(f)
+    meta = d.pop("_meta", {}) if isinstance(d.get("_meta"), dict) else {}
     prim, helpers = _TRAFFIC_GROUPS[group]
 
     def rows(prefixes):
         return [v for k, v in d.items() if any(k == p or k.startswith(p + ",") or k.startswith(p + ">") or
-                                               k.startswith(p + "<") for p in prefixes)]
+                                               k.startswith(p + "<") or k.startswith(p + "(") for p in prefixes)]
 
     calls = sum(v["calls"] for v in rows(prim))
     if calls == 0:
-        return None
+        return None, None
     tot = sum(v["calls"] * (v["fetch_bytes"] + v["write_bytes"]) for v in rows(prim + helpers))
-    return tot / calls
+    src = {"file": "profiles/" + os.path.basename(path), "commit": meta.get("commit"), "command": meta.get("command"),
+           "measured_in_this_run": False}
+    return tot / calls, src
 
 
 def cpu_baseline(kind="finetune", N=200, forward_only=False, budget_s=25.0):
@@ -164,6 +172,12 @@ def main():
     ap.add_argument("--cu-limit", type=int, default=0, help="experiment: getmi_set_cu_limit before the run")
     ap.add_argument("--model", choices=["finetune", "pretrain", "atac"], default="finetune",
                     help="finetune = the contract workload (BASELINE configs[1]); pretrain = C3; atac = C4")
+    ap.add_argument("--producer", action="store_true",
+                    help="draw every batch of the timed loop through data.RegionBatchProducer (device-side gather from "
+                         "HBM-resident peak tables, SURVEY 8 f3) instead of re-using one resident batch")
+    ap.add_argument("--no-extra-pass", action="store_true",
+                    help="skip the un-timed extra steps after the timed region that bracket the LayerNorm-backward kernel "
+                         "(roofline_hbm) and every GEMM / attention launch (kernels table) with HIP events")
     ap.add_argument("--inference", action="store_true",
                     help="forward only, eval mode, torch.inference_mode (SURVEY 8d C5); not the contract metric")
     args = ap.parse_args()
@@ -211,8 +225,28 @@ def main():
         opt = GO.configure_optimizer(model, ocfg)
     B, N = args.batch, args.regions
     batch = synthetic_batch(B, N, 1234 + rank, device)
+    batches = None
+    if args.producer:
+        # f3: a synthetic zarr-shaped store (4 cell types x 60 k peaks), tables resident in HBM; the host sends B window
+        # starts per step and the batch is gathered on the device
+        from get_model_amd import data as GD
+        store = GD.make_synthetic_store(num_peaks=60000, celltypes=("a", "b", "c", "d"), seed=rank,
+                                        chromosomes=tuple(f"chr{i}" for i in range(1, 9)))
+        ds = GD.RegionMotifDataset(store, sampling_step=100, num_region_per_sample=N, seed=1, quantitative_atac=False,
+                                   mask_ratio=0.5 if args.model == "pretrain" else 0.0)
+        producer = GD.RegionBatchProducer(ds, batch_size=B, device=device, shuffle=True, seed=2 + rank)
+
+        def endless():
+            while True:
+                for b in producer:
+                    yield b
+
+        batches = endless()
+
+    batch0 = batch
 
     def infer_step():
+        batch = next(batches) if batches is not None else batch0
         with torch.inference_mode():
             out = model(**model.get_input(batch))
             return (out[0] if isinstance(out, tuple) else out).float().mean()
@@ -222,6 +256,7 @@ def main():
     def step():
         if args.inference:
             return infer_step()
+        batch = next(batches) if batches is not None else batch0
         buckets.zero_grad()
         out = model(**model.get_input(batch))
         pred, obs = model.before_loss(out, batch)
@@ -252,16 +287,33 @@ def main():
     if not args.no_kernel_events:
         K.PROFILE = []
         # The dominant kernel group of a training step is known from the committed rocprofv3 kernel statistics of this
-        # same command (profiles/r02_bench_kernel_stats.csv: weight-gradient GEMMs 20.4 % of the step, next the plain
+        # same command (profiles/r03_bench_kernel_stats.csv: weight-gradient GEMMs 20.4 % of the step, next the plain
         # bf16 GEMMs 19.0 %), so only its launches carry events by default; forward-only runs have no wgrad: all groups.
         K.PROFILE_ONLY = None if (args.all_kernel_events or args.inference) else {DOMINANT_GROUP}
     opt_events.clear()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     prof, K.PROFILE = K.PROFILE, None
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    # ---- un-timed extra passes (after the timed region, so their events cannot perturb it) ----
+    extra_prof = ln_prof = None
+    if not args.no_kernel_events and not args.no_extra_pass and rank == 0 and world == 1:
+        K.PROFILE, K.PROFILE_ONLY = [], {"ln_bwd_kernel"}
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ln_prof, K.PROFILE, K.PROFILE_ONLY = K.PROFILE, [], None
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        extra_prof, K.PROFILE = K.PROFILE, None
     if world > 1:
         t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -286,13 +338,40 @@ def main():
                                  "time_share": sec / dt}
             dom = max(agg, key=lambda k: agg[k][1])
             fl, sec, n = agg[dom]
+            traffic, traffic_src = pmc_traffic(dom)
             roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom),
-                    "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r0N_pmc_traffic.json)",
+                    "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_BF16_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                     "launches": n, "avg_launch_us": sec / n * 1e6,
                     "events_on": "every GEMM / attention launch" if K.PROFILE_ONLY is None else
-                                 "this kernel group only (dominant by profiles/r02_bench_kernel_stats.csv; "
+                                 "this kernel group only (dominant by profiles/r03_bench_kernel_stats.csv; "
                                  "--all-kernel-events for the table)"}
+        # HBM-bound sibling (north_star: HBM GB/s of the norm kernels): LayerNorm backward, algorithmic bytes of each
+        # launch (kernels.layernorm_bwd) over HIP-event durations, from two extra un-timed steps
+        roof_hbm = None
+        if ln_prof:
+            by = sum(x[1] for x in ln_prof)
+            sec = sum(x[2].elapsed_time(x[3]) for x in ln_prof) * 1e-3
+            roof_hbm = {"bound": "hbm", "kernel": "ln_bwd_kernel", "achieved": by / sec / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": by / sec / 1e9 / PEAK_HBM_GBS, "launches": len(ln_prof),
+                        "avg_launch_us": sec / len(ln_prof) * 1e6, "bytes_per_launch": by / len(ln_prof),
+                        "measured": "HIP events on the launch stream, 2 un-timed steps after the timed region"}
+        if extra_prof:
+            agg = {}
+            for name, flops, e0, e1 in extra_prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += 1
+            for name, (fl, sec, n) in agg.items():
+                if name in kernels:
+                    continue
+                rec = {"launches_per_step": n / 2, "avg_us": sec / n * 1e6, "from": "2 un-timed steps with events on every launch"}
+                if name == "ln_bwd_kernel" or name == "ln_fwd_kernel":
+                    rec["gb_per_s"] = fl / sec / 1e9
+                else:
+                    rec["tflops"] = fl / sec / 1e12
+                kernels[name] = rec
         fpr = flop_per_region(args.model, N, args.layers, args.inference)
         loss_name = "MSE" if args.model == "pretrain" else "PoissonNLL"
         if args.inference:
@@ -313,7 +392,9 @@ def main():
             "flop_per_region": fpr,
             "e2e_mfma_frac": value * fpr / (world * PEAK_BF16_TFLOPS * 1e12),
             "optimizer_ms_per_step": (sum(a.elapsed_time(b) for a, b in opt_events) / len(opt_events)) if opt_events else None,
-            "roofline": roof, "kernels": kernels,
+            "ms_per_step_median": median_ms,
+            "batch_source": "RegionBatchProducer (device-side gather per step)" if args.producer else "one batch resident in HBM",
+            "roofline": roof, "roofline_hbm": roof_hbm, "kernels": kernels,
         }
     if world > 1:
         dist.barrier()

@@ -143,7 +143,9 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6):
     y = torch.empty(M, D, dtype=BF16, device=x.device)
     mean = torch.empty(M, dtype=F32, device=x.device)
     rstd = torch.empty(M, dtype=F32, device=x.device)
+    e0 = _prof_begin("ln_fwd_kernel")
     lib.call("getmi_layernorm_fwd", x, gamma, beta, y, mean, rstd, M, D, float(eps))
+    _prof_end(e0, "ln_fwd_kernel", float(M) * D * 6)         # algorithmic bytes: x fp32 in, y bf16 out
     return y, mean, rstd
 
 
@@ -159,8 +161,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, rowscale=None, rows_per_s
     dbeta = torch.empty(D, dtype=F32, device=dev)
     dbias = torch.empty(D, dtype=F32, device=dev) if want_dbias else None
     ws = _ws(lib.query("getmi_layernorm_bwd_workspace_bytes", M, D), dev)
+    e0 = _prof_begin("ln_bwd_kernel")
     lib.call("getmi_layernorm_bwd", dy, x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, dz, dgamma, dbeta,
              dbias, 0, M, D, ws, ws.numel())
+    # (for this HBM-bound kernel the profile's second field is its ALGORITHMIC BYTES, not FLOPs: dy bf16 + x fp32 +
+    #  dx fp32 (+ dres fp32) (+ dz bf16) per element)
+    _prof_end(e0, "ln_bwd_kernel", float(M) * D * (2 + 4 + 4 + (4 if dres is not None else 0) + (2 if want_dz else 0)))
     return dx, dz, dgamma, dbeta, dbias
 
 

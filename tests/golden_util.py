@@ -28,7 +28,7 @@ def load_case(name):
             k1 = (O.hash_tensor((B,), 9000 + seed * 100 + 2 * i, 0.0, 1.0) < 0.7).float()
             k2 = (O.hash_tensor((B,), 9001 + seed * 100 + 2 * i, 0.0, 1.0) < 0.7).float()
             keep.append((k1, k2))
-    return dict(z=z, kind=kind, L=L, B=B, N=N, train=bool(train), seed=seed, sd=sd, batch=batch, keep=keep)
+    return dict(name=name, z=z, kind=kind, L=L, B=B, N=N, train=bool(train), seed=seed, sd=sd, batch=batch, keep=keep)
 
 
 def _group_name(name):
@@ -47,8 +47,10 @@ def check_against_golden(case, loss, pred, grads, rtol_pred, rtol_loss, rtol_gno
     gp = torch.from_numpy(z["pred"])
     scale = gp.abs().max().item()
     err = (pred.detach().float().cpu() - gp).abs().max().item()
+    err_pred = err / scale
     assert err <= rtol_pred * scale, f"pred max-abs err {err:.3e} vs scale {scale:.3e}"
     gl = float(z["loss"])
+    err_loss = abs(float(loss) - gl) / abs(gl)
     assert abs(float(loss) - gl) <= rtol_loss * abs(gl), f"loss {float(loss)} vs golden {gl}"
     groups = {}
     for name, g in grads.items():
@@ -62,14 +64,18 @@ def check_against_golden(case, loss, pred, grads, rtol_pred, rtol_loss, rtol_gno
         e["got"].append(g[idx].float())
         e["ref"].append(vals)
     worst = 0.0
+    worst_norm = 0.0
     for name, e in groups.items():
         gn, rn = e["n2"] ** 0.5, e["ref_n2"] ** 0.5
+        worst_norm = max(worst_norm, abs(gn - rn) / max(rn, 1e-12))
         assert abs(gn - rn) <= rtol_gnorm * max(rn, 1e-12), f"{name}: |g|={gn} golden {rn}"
         got, ref = torch.cat(e["got"]), torch.cat(e["ref"])
         ref_scale = max(ref.abs().max().item(), rn / np.sqrt(e["numel"]), 1e-12)
         err = (got - ref).abs().max().item() / ref_scale
         worst = max(worst, err)
         assert err <= atol_gval_rel, f"{name}: sampled grad err {err:.3e} (normalised)"
+    print(f"MEASURED golden {case.get('name', '')}: pred err {err_pred:.2e} of max, loss err {err_loss:.2e}, worst gradient "
+          f"norm dev {worst_norm:.2e}, worst sampled gradient err {worst:.2e}")
     return worst
 
 

@@ -1,7 +1,7 @@
 """GPU: extreme and ragged batch shapes through the whole HIP path (forward, loss, backward) against the fp32 oracle:
 one sample, one region (T = 2 tokens), region counts around the kernels' 32 / 64 / 224 / 256 boundaries, a batch that does
-not fill one GEMM tile.  Same tolerances as tests/test_model_parity_gpu.py (prediction 2.5e-2 of max, loss 1e-2, gradient
-cosine >= 0.995 per tensor group)."""
+not fill one GEMM tile.  Bars about twice the worst value measured on MI355X (prediction 2.2e-2 of max: measured <= 1.07e-2;
+gradient cosine >= 0.998 per tensor: measured >= 0.99988); each case prints what it measured."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -40,8 +40,9 @@ def test_edge_shape_matches_oracle(kind, B, N):
     oloss, opred, ograds = O.loss_and_grads(kind, sd, batch, num_layers=L, drop_path_rate=0.0)
     assert torch.isfinite(p).all() and torch.isfinite(loss)
     perr = (p.reshape(opred.shape) - opred).abs().max().item() / max(opred.abs().max().item(), 1e-6)
-    assert perr <= 2.5e-2, f"pred err {perr}"
-    assert abs(loss.item() - oloss.item()) <= 1e-2 * abs(oloss.item()) + 1e-5, (loss.item(), oloss.item())
+    assert perr <= 2.2e-2, f"pred err {perr}"        # measured <= 1.07e-2 (one region: T = 2 tokens)
+    lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
+    assert lerr <= 1e-2, (loss.item(), oloss.item())
     gg, og = grouped(grads), grouped({k: v for k, v in ograds.items() if k in grads})
     worst = 1.0
     for n, g in gg.items():
@@ -57,4 +58,4 @@ def test_edge_shape_matches_oracle(kind, B, N):
             continue
         worst = min(worst, cos)
         assert cos >= 0.998, f"{n}: cosine {cos} (|ref| {float(ref.norm()):.3e})"
-    print(f"MEASURED edge shape {kind} B={B} N={N}: pred err {perr:.2e}, min cosine {worst:.5f}")
+    print(f"MEASURED edge shape {kind} B={B} N={N}: pred err {perr:.2e}, loss err {lerr:.2e}, min cosine {worst:.5f}")

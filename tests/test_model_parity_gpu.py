@@ -1,11 +1,15 @@
 """GPU: the full HIP path (model classes -> C ABI) against (a) the golden vectors captured from the reference
 and (b) the fp32 oracle run on the host, for every fixture: prediction, loss and ALL parameter gradients.
 
-Tolerances (bf16 MFMA operands, fp32 accumulate / residual stream):
-  prediction: max-abs error <= 2.5e-2 * max|pred|        loss: 1e-2 relative
-  gradients : per-parameter L2 norm within 4 %, sampled elements within 6 % of the sample's max-abs
-              (normalised max-abs), cosine similarity of the full gradient vs the oracle >= 0.995.
+Tolerances (bf16 MFMA operands, fp32 accumulate / residual stream), set in round 3 to about twice
+the worst value measured on MI355X over the seven fixtures (each test prints what it measured: `pytest -s`):
+  prediction: max-abs error <= 2e-2 * max|pred|  (measured <= 9.4e-3, at 12 layers)
+  loss      : 4.5e-3 relative                     (measured <= 2.1e-3)
+  gradients : per-parameter L2 norm within RTOL_GNORM, sampled elements within 6 % of the sample's max-abs (normalised
+              max-abs; measured <= 3.9e-2, the q_bias cancellation sum of the 3-layer train case), cosine similarity of
+              every full gradient tensor vs the oracle >= 0.9997 (measured >= 0.99989).
 """
+RTOL_PRED, RTOL_LOSS, RTOL_GNORM, ATOL_GVAL, MIN_COS = 2e-2, 4.5e-3, 4e-2, 6e-2, 0.9997
 import pytest
 import torch
 import torch.nn.functional as F
@@ -44,8 +48,8 @@ def test_hip_path_matches_reference_golden_and_oracle(name):
     c = load_case(name)
     loss, pred, grads = run_hip(c, c["train"])
     assert all(g is not None for g in grads.values()), [n for n, g in grads.items() if g is None]
-    worst = check_against_golden(c, loss.cpu(), pred.cpu(), grads, rtol_pred=2.5e-2, rtol_loss=1e-2, rtol_gnorm=4e-2,
-                                 atol_gval_rel=6e-2)
+    worst = check_against_golden(c, loss.cpu(), pred.cpu(), grads, rtol_pred=RTOL_PRED, rtol_loss=RTOL_LOSS,
+                                 rtol_gnorm=RTOL_GNORM, atol_gval_rel=ATOL_GVAL)
     # full-tensor comparison against the oracle (the golden file only samples gradients)
     torch.set_num_threads(16)
     oloss, opred, ograds = O.loss_and_grads(c["kind"], c["sd"], c["batch"], num_layers=c["L"], keep_masks=c["keep"])
@@ -55,7 +59,7 @@ def test_hip_path_matches_reference_golden_and_oracle(name):
         ref = og[n]
         cos = F.cosine_similarity(g, ref, dim=0).item()
         min_cos = min(min_cos, cos)
-        assert cos >= 0.995, f"{n}: cosine vs oracle {cos}"
+        assert cos >= MIN_COS, f"{n}: cosine vs oracle {cos}"
     perr = (pred.cpu() - opred).abs().max().item() / opred.abs().max().item()
     print(f"{name}: pred err {perr:.2e} of max, loss {loss.item():.6f} vs {oloss.item():.6f}, "
           f"worst sampled grad err {worst:.2e}, min grad cosine {min_cos:.5f}")

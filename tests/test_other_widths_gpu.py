@@ -36,12 +36,13 @@ def test_other_widths_match_oracle(kind, D, H, L, motif):
     torch.set_num_threads(16)
     oloss, opred, ograds = O.loss_and_grads(kind, sd, batch, num_layers=L, num_heads=H, drop_path_rate=0.0)
     perr = (p.reshape(opred.shape) - opred).abs().max().item() / opred.abs().max().item()
-    assert perr <= 2.5e-2, f"pred err {perr}"
+    print(f"MEASURED other width: pred err {perr:.2e}, loss err {abs(loss.item() - oloss.item()) / abs(oloss.item()):.2e}")
+    assert perr <= 2e-2, f"pred err {perr}"
     assert abs(loss.item() - oloss.item()) <= 1e-2 * abs(oloss.item()), (loss.item(), oloss.item())
     gg, og = grouped(grads), grouped({k: v for k, v in ograds.items() if k in grads})
     for n, g in gg.items():
         cos = F.cosine_similarity(g.flatten().float().cpu(), og[n].flatten(), dim=0).item()
-        assert cos >= 0.995, f"{n}: cosine {cos}"
+        assert cos >= 0.998, f"{n}: cosine {cos}"
 
 
 def test_unsupported_head_width_is_refused():

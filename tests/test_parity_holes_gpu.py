@@ -7,8 +7,8 @@
   * `region_embed(x)` on its own and `concat_cls` on a foreign tensor;
   * a parameter used by two graph nodes of ONE backward with ddp.GradBuckets active (ADVICE r1);
   * the side-stream weight-gradient mode (GETMI_WGRAD_STREAM=1).
-Tolerances as in test_model_parity_gpu.py (bf16 MFMA operands, fp32 accumulate): pred 2.5e-2 of max|pred|,
-gradients / Jacobians 6 % of the tensor's scale on sampled elements, 4 % on norms, cosine >= 0.995.
+Tolerances as in test_model_parity_gpu.py (bf16 MFMA operands, fp32 accumulate): pred 2e-2 of max|pred| (PRED), loss 4.5e-3,
+gradients / Jacobians 6 % of the tensor's scale on sampled elements, 4 % on norms, cosine >= 0.9995; printed as MEASURED.
 """
 import os
 
@@ -20,6 +20,15 @@ import torch.nn.functional as F
 from tests.golden_util import golden_names, load_case
 
 pytestmark = pytest.mark.gpu
+PRED = 2e-2
+
+
+def _perr(tag, got, ref, bar=PRED):
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"MEASURED {tag}: pred err {err:.2e} of max")
+    assert err <= bar, (tag, err)
+
+
 EXTRA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_extra")
 
 
@@ -54,14 +63,14 @@ def test_forward_only_matches_reference_golden_and_oracle(name, mode):
     gold = torch.from_numpy(c["z"]["pred"])
     scale = gold.abs().max().item()
     assert got.shape == gold.shape
-    assert (got - gold).abs().max().item() <= 2.5e-2 * scale
-    assert abs(loss.item() - float(c["z"]["loss"])) <= 1e-2 * abs(float(c["z"]["loss"]))
+    _perr(f"forward-only {name} {mode} vs golden", got, gold)
+    assert abs(loss.item() - float(c["z"]["loss"])) <= 4.5e-3 * abs(float(c["z"]["loss"]))
     torch.set_num_threads(16)
     if c["kind"] == "pretrain":
         _, opred = O.pretrain_loss(c["sd"], c["batch"], num_layers=c["L"])
     else:
         _, opred = O.finetune_loss(c["sd"], c["batch"], kind=c["kind"], num_layers=c["L"])
-    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    _perr(f"forward-only {name} {mode} vs oracle", got, opred)
     # the forward-only epilogue must give the same numbers as the training forward (which also stores gelu')
     out_t = model(**model.get_input(batch))
     pred_t, _ = model.before_loss(out_t, batch)
@@ -87,7 +96,7 @@ def test_c5_large_batch_inference_slice_against_the_oracle():
     torch.set_num_threads(16)
     opred = O.finetune_forward(sd, rm[idx], num_layers=L)
     got = pred[idx].float().cpu()
-    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    _perr("C5 B=1024 slice", got, opred)
     # repeated samples give repeated predictions (no cross-sample leakage through tile tails)
     assert torch.equal(pred[0], pred[8]) and torch.equal(pred[3], pred[B - 13])
 
@@ -105,7 +114,7 @@ def test_c2_full_batch_slice_against_the_oracle():
     torch.set_num_threads(16)
     opred = O.finetune_forward(sd, batch["region_motif"][idx], num_layers=L)
     got = pred[idx].detach().float().cpu()
-    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    _perr("C2 B=256 slice", got, opred)
 
 
 def test_c3_full_batch_pretrain_slice_against_the_oracle():
@@ -132,7 +141,7 @@ def test_c3_full_batch_pretrain_slice_against_the_oracle():
     _, opred = O.pretrain_loss(sd, sub, num_layers=L)
     got = torch.cat([got_all[int(start[i]):int(start[i] + cnt[i])] for i in idx])
     assert got.shape == opred.shape
-    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    _perr("C3 pretrain B=256 slice", got, opred)
     # the targets handed to the loss are the original rows of the masked regions, in the same order
     want = torch.cat([batch["region_motif"][i][batch["mask"][i].bool()] for i in idx])
     assert torch.equal(torch.cat([obs_all[int(start[i]):int(start[i] + cnt[i])] for i in idx]), want)
@@ -156,7 +165,7 @@ def test_c4_long_context_atac_slice_against_the_oracle():
     torch.set_num_threads(16)
     _, opred = O.finetune_loss(sd, {k: v[idx] for k, v in batch.items()}, kind="atac", num_layers=L)
     got = pred[key][idx].detach().float().cpu()
-    assert (got - opred).abs().max().item() <= 2.5e-2 * opred.abs().max().item()
+    _perr("C4 atac N=2000 slice", got, opred)
     loss = model.after_loss(model.loss(pred, obs))
     loss.backward()
     g_full = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
@@ -245,7 +254,8 @@ def test_interpretation_hooks_and_input_jacobian_match_the_reference():
     op.backward(m.cpu())
     for name, ref_t in (("input", leaf), ("region_embed", x_emb), ("encoder.blocks.1", x1)):
         cos = F.cosine_similarity(tensors[name].grad.float().cpu().flatten(), ref_t.grad.flatten(), dim=0).item()
-        assert cos >= 0.995, f"d{name}: cosine vs oracle {cos}"
+        print(f"MEASURED interpretation d{name}: cosine vs oracle {cos:.6f}")
+        assert cos >= 0.9995, f"d{name}: cosine vs oracle {cos}"
 
 
 def test_region_embed_alone_and_concat_cls_of_a_foreign_tensor():

@@ -135,9 +135,10 @@ def test_train_step_with_the_products_own_drop_path_draw_matches_the_oracle():
     errs = _grad_errors({n: p.grad for n, p in m.named_parameters()}, og)
     print(f"MEASURED own-draw train step: {dropped} branch drops, pred err {perr:.2e}, loss err {lerr:.2e}")
     _report("own-draw train step grads", errs)
-    assert perr <= 1.5e-2 and lerr <= 4e-3
+    # measured on MI355X: pred 6.0e-3, loss 2.2e-3, gradients max-abs 8.6e-3 / norm 2.9e-3 / cosine 0.99995
+    assert perr <= 1.2e-2 and lerr <= 4.5e-3
     for n, (e, nr, cos) in errs.items():
-        assert e <= 6e-2 and nr <= 3e-2 and cos >= 0.998, (n, e, nr, cos)
+        assert e <= 2e-2 and nr <= 8e-3 and cos >= 0.9998, (n, e, nr, cos)
 
 
 def test_c2_shape_every_gradient_against_the_oracle():
@@ -159,9 +160,10 @@ def test_c2_shape_every_gradient_against_the_oracle():
     _report("C2 shape L=2 grads", errs)
     for n, (e, nr, cos) in sorted(errs.items(), key=lambda kv: -kv[1][0])[:5]:
         print(f"MEASURED   {n}: max-abs {e:.3e} norm dev {nr:.3e} cos {cos:.6f}")
-    assert perr <= 1.5e-2 and lerr <= 2e-3
+    # measured on MI355X: pred 5.6e-3, loss 1.8e-3, gradients max-abs 6.6e-3 / norm 3.5e-3 / cosine 0.999989
+    assert perr <= 1.2e-2 and lerr <= 4e-3
     for n, (e, nr, cos) in errs.items():
-        assert e <= 5e-2 and nr <= 2e-2 and cos >= 0.999, (n, e, nr, cos)
+        assert e <= 1.5e-2 and nr <= 8e-3 and cos >= 0.9999, (n, e, nr, cos)
 
 
 def test_c2_shape_twelve_layers_input_gradient_of_four_samples():
@@ -191,7 +193,8 @@ def test_c2_shape_twelve_layers_input_gradient_of_four_samples():
     perr = (pred[idx].detach().float().cpu() - opred).abs().max().item() / opred.abs().max().item()
     print(f"MEASURED C2 shape L=12 d loss/d region_motif (4 samples): max-abs {err:.3e}, norm dev {nr:.3e}, "
           f"cosine {cos:.6f}; pred err {perr:.2e}")
-    assert err <= 6e-2 and nr <= 2e-2 and cos >= 0.998 and perr <= 2e-2
+    # measured on MI355X: max-abs 9.8e-3, norm 5.1e-3, cosine 0.999978, pred 8.1e-3
+    assert err <= 2e-2 and nr <= 1.1e-2 and cos >= 0.9999 and perr <= 1.7e-2
     # and the weight gradients at this depth and size stay finite and non-trivial
     for n, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max().item() > 0, n
@@ -254,9 +257,10 @@ def test_lora_parametrised_linear_weights_train_through_the_fused_block():
     errs = _grad_errors(got, want)
     print(f"MEASURED LoRA: loss err {lerr:.2e}, pred err {perr:.2e}")
     _report("LoRA factor grads", errs)
-    assert lerr <= 4e-3 and perr <= 1.5e-2
+    # measured on MI355X: loss 2.0e-3, pred 5.0e-3, factor gradients max-abs 8.2e-3 / norm 4.9e-3 / cosine 0.999975
+    assert lerr <= 4e-3 and perr <= 1.1e-2
     for n, (e, nr, cos) in errs.items():
-        assert e <= 5e-2 and nr <= 3e-2 and cos >= 0.998, (n, e, nr, cos)
+        assert e <= 2e-2 and nr <= 1e-2 and cos >= 0.9999, (n, e, nr, cos)
     # frozen base weights and everything else got no gradient
     for n, p in m.named_parameters():
         if "lora_" not in n:
@@ -315,7 +319,7 @@ def test_shipped_checkpoint_maps_load_and_predict_on_the_gpu(tmp_path):
         perr = (pred.float().cpu() - opred).abs().max().item() / opred.abs().max().item()
         lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
         print(f"MEASURED checkpoint map {ci} ({kind}): pred err {perr:.2e}, loss err {lerr:.2e}")
-        assert perr <= 1.5e-2 and lerr <= 4e-3
+        assert perr <= 1.6e-2 and lerr <= 5e-3          # measured <= 7.6e-3 / 2.3e-3
         # export -> import round trip on the GPU model (Lightning layout)
         back = C.save_checkpoint(m, str(tmp_path / f"back{ci}.ckpt"))
         m2 = build_model(region_model_yaml(kind, num_layers=L))
@@ -356,21 +360,26 @@ def test_fp16_autocast_with_grad_scaler_two_steps_follow_the_oracle():
         lerr = abs(loss.item() - oloss.item()) / abs(oloss.item())
         print(f"MEASURED fp16-mixed step {step}: loss err {lerr:.2e}, scaled |dW| max {big:.3e}")
         _report(f"fp16-mixed step {step} grads", errs)
-        assert lerr <= 5e-3
+        assert lerr <= 4.5e-3                           # measured 2.1e-3; gradients 6.5e-3 / 2.3e-3 / 0.99997
         for n, (e, nr, cos) in errs.items():
-            assert e <= 6e-2 and nr <= 3e-2 and cos >= 0.998, (step, n, e, nr, cos)
+            assert e <= 2e-2 and nr <= 1e-2 and cos >= 0.9995, (step, n, e, nr, cos)
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
         scaler.step(opt)
         scaler.update()
         ropt.step()
         assert scaler.get_scale() == 2.0 ** 16          # no overflow was found
-    # after two steps the weights moved the same way
-    for n, p in m.named_parameters():
-        d_got = p.detach().cpu() - sd[n]
-        d_ref = ref[n].detach() - sd[n]
-        if d_ref.norm().item() < 1e-9:
-            continue
-        cos = F.cosine_similarity(d_got.flatten(), d_ref.flatten(), dim=0).item()
-        assert cos >= 0.97, (n, cos)
+        # the unscaled gradients drove the same update (Adam normalises, so compare directions of the whole update)
+        worst = 1.0
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                d_got = (p.detach() - before[n]).cpu()
+                d_ref = ref[n].detach() - before[n].cpu()
+                if d_ref.norm().item() < 1e-12:
+                    continue
+                worst = min(worst, F.cosine_similarity(d_got.flatten(), d_ref.flatten(), dim=0).item())
+                ref[n].copy_(p.detach().cpu())      # step 1 compares gradients at the SAME point of weight space
+        print(f"MEASURED fp16-mixed step {step}: min cosine of the AdamW update vs the oracle's {worst:.5f}")
+        assert worst >= 0.97
 
 
 # ---------------------------------------------------------------------------------------------------------------
