@@ -29,8 +29,8 @@ int getmi_gemm_wgrad_impl(const bf16_t* X, const bf16_t* Y, int M, int N1, int N
                           int accumulate, float* slabs, size_t slab_bytes, hipStream_t st);
 int getmi_ln_fwd_impl(const float*, const float*, const float*, bf16_t*, float*, float*, int, int, float, hipStream_t);
 size_t getmi_ln_bwd_workspace_bytes(int M, int D);
-int getmi_ln_bwd_impl(const bf16_t*, const float*, const float*, const float*, const float*, const float*, const float*,
-                      int, float*, bf16_t*, float*, float*, float*, int, int, int, void*, size_t, hipStream_t);
+int getmi_ln_bwd_impl(const bf16_t*, const float*, const float*, const float*, const float*, const void*, int, const float*,
+                      int, void*, int, bf16_t*, float*, float*, float*, int, int, int, void*, size_t, hipStream_t);
 int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, bf16_t*, float*, int, int, int, float, hipStream_t);
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H);
 int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, float*, float*, int, int, int,
@@ -122,8 +122,16 @@ int getmi_layernorm_bwd(const void* dy, const float* x, const float* mean, const
                         const float* dres, const float* rowscale, int rows_per_sample, float* dx, void* dz, float* dgamma,
                         float* dbeta, float* dbias_prev, int accumulate, int M, int D, void* workspace,
                         size_t workspace_bytes, void* stream) {
-    return getmi_ln_bwd_impl(BF(dy), x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, BFW(dz), dgamma, dbeta,
+    return getmi_ln_bwd_impl(BF(dy), x, mean, rstd, gamma, dres, 0, rowscale, rows_per_sample, dx, 0, BFW(dz), dgamma, dbeta,
                              dbias_prev, accumulate, M, D, workspace, workspace_bytes, ST(stream));
+}
+int getmi_layernorm_bwd_stream(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const void* dres, int dres_is_bf16, const float* rowscale, int rows_per_sample, void* dx,
+                               int dx_is_bf16, void* dz, float* dgamma, float* dbeta, float* dbias_prev, int accumulate, int M,
+                               int D, void* workspace, size_t workspace_bytes, void* stream) {
+    return getmi_ln_bwd_impl(BF(dy), x, mean, rstd, gamma, dres, dres_is_bf16 != 0, rowscale, rows_per_sample, dx,
+                             dx_is_bf16 != 0, BFW(dz), dgamma, dbeta, dbias_prev, accumulate, M, D, workspace, workspace_bytes,
+                             ST(stream));
 }
 int getmi_attention_fwd(const void* qkv, void* out, void* out_lo, float* lse, int B, int T, int H, float scale,
                         void* stream) {

@@ -51,16 +51,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-template <int NV>
+// RB / XB: the residual-gradient stream comes in (dres) / goes out (dx) as bf16 instead of fp32 (the "bf16 gradient
+// stream", GETMI_BF16_GRAD in functional.py: 12 instead of 16 bytes per element).  zsum: accumulate the column sums of
+// bf16(rowscale * dx) even when dz is null (with rowscale == null and XB the caller uses dx itself as dz).
+template <int NV, bool RB, bool XB>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     const float* __restrict__ gamma, const void* __restrict__ dres_,
                                                      const float* __restrict__ rowscale, int rows_per_sample,
-                                                     float* __restrict__ dx, bf16_t* __restrict__ dz,
-                                                     float* __restrict__ partial, int M) {
+                                                     void* __restrict__ dx_, bf16_t* __restrict__ dz,
+                                                     float* __restrict__ partial, int M, int zsum) {
     constexpr int D = NV * 256;
     __shared__ __attribute__((aligned(16))) float red[3][4][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* dres = reinterpret_cast<const float*>(dres_);
+    const bf16_t* dresb = reinterpret_cast<const bf16_t*>(dres_);
+    float* dx = reinterpret_cast<float*>(dx_);
+    bf16_t* dxb = reinterpret_cast<bf16_t*>(dx_);
     float4 g[NV], ag[NV], ab[NV], az[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const int stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
     float4 nx[NV], nr[NV];
-    uint2 nd[NV];
+    uint2 nd[NV], nrb[NV];
     float nmu = 0.f, nrs = 0.f;
     auto issue = [&](int r) {
         nmu = mean[r];
@@ -83,7 +90,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int v = 0; v < NV; ++v) {
             nx[v] = load_f4<kNtLn>(x + (size_t)r * D + (v * 64 + lane) * 4);
             nd[v] = load_u2<kNtLn>(dy + (size_t)r * D + (v * 64 + lane) * 4);
-            if (dres) nr[v] = load_f4<kNtLn>(dres + (size_t)r * D + (v * 64 + lane) * 4);
+            if (dres_) {
+                if constexpr (RB) nrb[v] = load_u2<kNtLn>(dresb + (size_t)r * D + (v * 64 + lane) * 4);
+                else nr[v] = load_f4<kNtLn>(dres + (size_t)r * D + (v * 64 + lane) * 4);
+            }
         }
     };
     if (row < M) issue(row);
@@ -96,7 +106,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int v = 0; v < NV; ++v) {
             const float4 xv = nx[v];
             const uint2 dv = nd[v];
-            rv[v] = dres ? nr[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!dres_) rv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if constexpr (RB)
+                rv[v] = make_float4(bf2f(nrb[v].x & 0xffff), bf2f(nrb[v].x >> 16), bf2f(nrb[v].y & 0xffff), bf2f(nrb[v].y >> 16));
+            else rv[v] = nr[v];
             xh[v] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
             d[v] = make_float4(bf2f(dv.x & 0xffff), bf2f(dv.x >> 16), bf2f(dv.y & 0xffff), bf2f(dv.y >> 16));
         }
@@ -117,10 +130,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             float4 o = make_float4(rs * (d[v].x - c1 - xh[v].x * c2), rs * (d[v].y - c1 - xh[v].y * c2),
                                    rs * (d[v].z - c1 - xh[v].z * c2), rs * (d[v].w - c1 - xh[v].w * c2));
             o.x += rv[v].x; o.y += rv[v].y; o.z += rv[v].z; o.w += rv[v].w;
-            store_f4<kNtLn>(dx + (size_t)row * D + (v * 64 + lane) * 4, o);
-            if (dz) {
+            if constexpr (XB) store_u2<kNtLn>(dxb + (size_t)row * D + (v * 64 + lane) * 4, pack4bf(o.x, o.y, o.z, o.w));
+            else store_f4<kNtLn>(dx + (size_t)row * D + (v * 64 + lane) * 4, o);
+            if (dz || zsum) {
                 const float4 z = make_float4(o.x * sc, o.y * sc, o.z * sc, o.w * sc);
-                store_u2<kNtLn>(dz + (size_t)row * D + (v * 64 + lane) * 4, pack4bf(z.x, z.y, z.z, z.w));
+                if (dz) store_u2<kNtLn>(dz + (size_t)row * D + (v * 64 + lane) * 4, pack4bf(z.x, z.y, z.z, z.w));
                 az[v].x += z.x; az[v].y += z.y; az[v].z += z.z; az[v].w += z.w;
             }
         }
@@ -201,21 +215,31 @@ int getmi_ln_fwd_impl(const float* x, const float* gamma, const float* beta, bf1
 
 size_t getmi_ln_bwd_workspace_bytes(int M, int D) { return (size_t)3 * ln_grid(M) * D * sizeof(float); }
 
-// dgamma/dbeta/dbias_prev: [D] each (dbias_prev may be null); accumulate: add into existing values
+// dgamma/dbeta/dbias_prev: [D] each (dbias_prev may be null); accumulate: add into existing values.
+// dres_bf16 / dx_bf16: element type of the residual-gradient stream on the way in / out (0 = fp32, 1 = bf16).
+// dz may be null with dbias_prev set only when rowscale is null and dx is bf16 (then dz == dx bit for bit).
 int getmi_ln_bwd_impl(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                      const float* dres, const float* rowscale, int rows_per_sample, float* dx, bf16_t* dz,
-                      float* dgamma, float* dbeta, float* dbias_prev, int accumulate, int M, int D, void* workspace,
-                      size_t workspace_bytes, hipStream_t st) {
+                      const void* dres, int dres_bf16, const float* rowscale, int rows_per_sample, void* dx, int dx_bf16,
+                      bf16_t* dz, float* dgamma, float* dbeta, float* dbias_prev, int accumulate, int M, int D,
+                      void* workspace, size_t workspace_bytes, hipStream_t st) {
     GETMI_CHECK_ARG(M > 0, "ln_bwd: M=%d", M);
     GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "ln_bwd: D=%d unsupported", D);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_ln_bwd_workspace_bytes(M, D), "ln_bwd: workspace too small");
     GETMI_CHECK_ARG(!rowscale || rows_per_sample > 0, "ln_bwd: rows_per_sample");
-    GETMI_CHECK_ARG(!dbias_prev || dz, "ln_bwd: dbias_prev needs dz");
+    GETMI_CHECK_ARG(!dbias_prev || dz || (dx_bf16 && !rowscale), "ln_bwd: dbias_prev needs dz (or a bf16 dx without a row scale)");
     const int g = ln_grid(M);
+    const int zsum = (dbias_prev != nullptr && dz == nullptr) ? 1 : 0;
     float* partial = reinterpret_cast<float*>(workspace);
+#define LN_BWD_LAUNCH2(NV, RB, XB)                                                                                \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, RB, XB>), dim3(g), dim3(256), 0, st, dy, x, mean, rstd, gamma, dres,   \
+                       rowscale, rows_per_sample, dx, dz, partial, M, zsum)
 #define LN_BWD_LAUNCH(NV)                                                                                         \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(g), dim3(256), 0, st, dy, x, mean, rstd, gamma, dres, rowscale,   \
-                       rows_per_sample, dx, dz, partial, M)
+    do {                                                                                                          \
+        if (dres_bf16 && dx_bf16) LN_BWD_LAUNCH2(NV, true, true);                                                 \
+        else if (dres_bf16) LN_BWD_LAUNCH2(NV, true, false);                                                      \
+        else if (dx_bf16) LN_BWD_LAUNCH2(NV, false, true);                                                        \
+        else LN_BWD_LAUNCH2(NV, false, false);                                                                    \
+    } while (0)
     switch (D / 256) {
         case 1: LN_BWD_LAUNCH(1); break;
         case 2: LN_BWD_LAUNCH(2); break;
@@ -223,6 +247,7 @@ int getmi_ln_bwd_impl(const bf16_t* dy, const float* x, const float* mean, const
         case 4: LN_BWD_LAUNCH(4); break;
     }
 #undef LN_BWD_LAUNCH
+#undef LN_BWD_LAUNCH2
     GETMI_CHECK_LAUNCH("ln_bwd");
     if (int rc = getmi_colreduce_impl(partial, dgamma, dbeta, dbias_prev, g, D, accumulate, st)) return rc;
     return GETMI_OK;

@@ -182,6 +182,56 @@ _ATTN_LO = os.environ.get("GETMI_ATTN_LO", "1") != "0"          # 0: delta from 
 HANDOFF = _GradHandoff()
 
 
+class _GradStream:
+    """bf16 gradient stream between consecutive encoder blocks (GETMI_BF16_GRAD=1).
+
+    PyTorch's engine casts every gradient to the dtype of the forward tensor it belongs to, and the residual stream is
+    fp32, so a bf16 dx cannot travel through autograd itself without a cast pass that would cost more than it saves.
+    The bf16 tensor travels HERE instead, keyed by an id the producing block gave its forward output, and autograd is
+    handed a zero-stride all-zero placeholder of the right shape (no memory, no kernel).  The consumer (the block that
+    produced that forward tensor) takes the slot; if the gradient autograd delivers is not the placeholder itself --
+    a hook changed it, or a second consumer of the tensor added its own contribution to the zeros -- that tensor is
+    ADDED to the slot's gradient, so the result stays right.  The one thing the placeholder would get wrong is somebody
+    LOOKING at the gradient of a block's output (retain_grad, tensor hooks: the interpretation mode of run.py:359-384);
+    the producer checks the forward tensor for those and then returns the real fp32 gradient through autograd instead."""
+
+    def __init__(self):
+        self.slots = {}
+        self.counter = 0
+        self.zero = {}
+
+    def new_id(self):
+        self.counter += 1
+        return self.counter
+
+    def put(self, gid, payload):
+        if len(self.slots) > 64:          # slots whose consumer never ran (an exception in backward): drop them
+            self.slots.clear()
+        self.slots[gid] = payload
+
+    def take(self, gid):
+        return self.slots.pop(gid, None) if gid is not None else None
+
+    def placeholder(self, shape, device):
+        z = self.zero.get(device)
+        if z is None:
+            z = self.zero[device] = torch.zeros((), dtype=torch.float32, device=device)
+        return z.expand(shape)
+
+    def is_placeholder(self, t):
+        z = self.zero.get(t.device)
+        return z is not None and t.data_ptr() == z.data_ptr() and all(st == 0 for st in t.stride())
+
+    @staticmethod
+    def observed(t):
+        """Somebody may look at t.grad or hook it: the real gradient has to go through autograd."""
+        return t is None or t.retains_grad or bool(getattr(t, "_backward_hooks", None))
+
+
+_BF16_GRAD = os.environ.get("GETMI_BF16_GRAD", "0") == "1"
+STREAM = _GradStream()
+
+
 def _pad_to(n, m):
     return (n + m - 1) // m * m
 
@@ -347,7 +397,15 @@ class EncoderBlock(torch.autograd.Function):
         ctx.weights = (qkv_w, proj_w, fc1_w, fc2_w)
         ctx.dims = (B, T, D, H, att_scale)
         ctx.up = (bool(up_block), up_scale)
-        return x_out.view(B, T, D)
+        out = x_out.view(B, T, D)
+        ctx.gids = (None, None)
+        ctx.x_ref = None
+        if _BF16_GRAD and needs_bwd:
+            gid = STREAM.new_id()
+            ctx.gids = (getattr(x, "_getmi_gid", None) if up_block else None, gid)
+            ctx.x_ref = x if up_block else None         # looked at in backward: is anybody observing its gradient?
+            out._getmi_gid = gid
+        return out
 
     @staticmethod
     def backward(ctx, dx_out):
@@ -357,13 +415,30 @@ class EncoderBlock(torch.autograd.Function):
         M = B * T
         dev = dx_out.device
         need = ctx.needs_input_grad
-        dx_out = dx_out.reshape(M, D).contiguous()
         side = _SideStream(dev)
-        # ---- MLP branch ----
-        # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
-        #  operand, so it waits only for the operand's producer and the two run side by side)
-        hit = HANDOFF.take(dx_out, scale2)
-        dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
+        in_gid, out_gid = ctx.gids
+        slot = STREAM.take(out_gid)
+        sdt = BF16 if _BF16_GRAD else torch.float32       # element type of the residual-gradient stream inside the block
+        if slot is not None:
+            # bf16 gradient stream: the consumer of this block's output left dx (bf16), dz2 and the fc2 bias gradient
+            dxb, sc_, dz2, dfc2_b = slot
+            same_scale = (sc_ is None and scale2 is None) or (sc_ is not None and scale2 is not None and
+                                                               sc_.data_ptr() == scale2.data_ptr())
+            if STREAM.is_placeholder(dx_out):
+                dx_out = dxb
+                if not same_scale:          # (cannot happen with GETTransformer's wiring; kept correct anyway)
+                    dx_out = dxb.float()
+                    dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+            else:       # autograd delivered more than the placeholder (a hook, a second consumer of the block's
+                dx_out = dxb.float().add_(dx_out.reshape(M, D))       # output): add it; fp32 from here on
+                dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+        else:
+            dx_out = dx_out.reshape(M, D).contiguous()
+            # ---- MLP branch ----
+            # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
+            #  operand, so it waits only for the operand's producer and the two run side by side)
+            hit = HANDOFF.take(dx_out, scale2)
+            dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
         dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
@@ -373,7 +448,7 @@ class EncoderBlock(torch.autograd.Function):
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
         dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
-                                                           want_dbias=True)
+                                                           want_dbias=True, dx_dtype=sdt)
         # ---- attention branch ----
         # (attn.proj's weight gradient has 9 output tiles: it shares a launch with attn.qkv's further down)
         pair = need[6] and need[3] and side.side is None
@@ -396,13 +471,22 @@ class EncoderBlock(torch.autograd.Function):
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
         up_block, up_scale = ctx.up
+        # the gradient handed to the block below: bf16 through STREAM when that block will take it and nobody is
+        # watching the tensor's gradient; else fp32 through autograd (with the dz hand-off of _GradHandoff)
+        to_stream = _BF16_GRAD and up_block and in_gid is not None and need[0] and not STREAM.observed(ctx.x_ref)
         dx_in, dz_up, dn1w, dn1b, dbias_up = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid,
                                                              rowscale=up_scale if up_block else None,
-                                                             rows_per_sample=T, want_dz=up_block, want_dbias=up_block)
-        if up_block:
-            HANDOFF.put(dx_in, up_scale, dz_up, dbias_up)
+                                                             rows_per_sample=T, want_dz=up_block, want_dbias=up_block,
+                                                             dx_dtype=BF16 if to_stream else torch.float32)
+        if to_stream:
+            STREAM.put(in_gid, (dx_in, up_scale, dz_up, dbias_up))
+            dx_ret = STREAM.placeholder((B, T, D), dev)
+        else:
+            if up_block:
+                HANDOFF.put(dx_in, up_scale, dz_up, dbias_up)
+            dx_ret = dx_in.view(B, T, D)
         side.join()
-        return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
+        return (dx_ret, dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
                 dfc1_b, dfc2_w, dfc2_b, None, None, None, None, None, None)
 
 
@@ -419,6 +503,8 @@ class FinalNorm(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, w)
         ctx.dims = (B, T, D)
         ctx.up = (bool(up_block), up_scale)      # as in EncoderBlock.forward
+        ctx.in_gid = getattr(x, "_getmi_gid", None) if (_BF16_GRAD and up_block) else None
+        ctx.x_ref = x if ctx.in_gid is not None else None
         return y.view(B, T, D)
 
     @staticmethod
@@ -429,9 +515,14 @@ class FinalNorm(torch.autograd.Function):
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         up_block, up_scale = ctx.up
+        to_stream = ctx.in_gid is not None and ctx.needs_input_grad[0] and not STREAM.observed(ctx.x_ref)
         dx, dz_up, dw, db, dbias_up = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach(),
                                                       rowscale=up_scale if up_block else None, rows_per_sample=T,
-                                                      want_dz=up_block, want_dbias=up_block)
+                                                      want_dz=up_block, want_dbias=up_block,
+                                                      dx_dtype=BF16 if to_stream else torch.float32)
+        if to_stream:       # see _GradStream
+            STREAM.put(ctx.in_gid, (dx, up_scale, dz_up, dbias_up))
+            return STREAM.placeholder((B, T, D), dy.device), dw, db, None, None, None
         if up_block:
             HANDOFF.put(dx, up_scale, dz_up, dbias_up)
         return dx.view(B, T, D), dw, db, None, None, None

@@ -150,24 +150,34 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, rowscale=None, rows_per_sample=0, want_dz=False,
-                  want_dbias=False):
-    """Returns (dx fp32, dz bf16|None, dgamma, dbeta, dbias_prev|None)."""
+                  want_dbias=False, dx_dtype=F32):
+    """Returns (dx, dz bf16|None, dgamma, dbeta, dbias_prev|None).  dres may be fp32 or bf16; dx_dtype picks the element
+    type of dx (the "bf16 gradient stream" of functional.py passes bf16 on both sides).  With a bf16 dx and no row scale
+    dz IS dx (same tensor: the kernel does not write it twice)."""
     _chk(dy, x, mean, rstd, gamma, dres, rowscale)
     M, D = x.shape
     dev = x.device
-    dx = torch.empty(M, D, dtype=F32, device=dev)
-    dz = torch.empty(M, D, dtype=BF16, device=dev) if want_dz else None
+    dx = torch.empty(M, D, dtype=dx_dtype, device=dev)
+    alias = want_dz and dx_dtype == BF16 and rowscale is None
+    dz = torch.empty(M, D, dtype=BF16, device=dev) if (want_dz and not alias) else None
     dgamma = torch.empty(D, dtype=F32, device=dev)
     dbeta = torch.empty(D, dtype=F32, device=dev)
     dbias = torch.empty(D, dtype=F32, device=dev) if want_dbias else None
     ws = _ws(lib.query("getmi_layernorm_bwd_workspace_bytes", M, D), dev)
     e0 = _prof_begin("ln_bwd_kernel")
-    lib.call("getmi_layernorm_bwd", dy, x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, dz, dgamma, dbeta,
-             dbias, 0, M, D, ws, ws.numel())
+    res_b = dres is not None and dres.dtype == BF16
+    if res_b or dx_dtype == BF16:
+        lib.call("getmi_layernorm_bwd_stream", dy, x, mean, rstd, gamma, dres, int(res_b), rowscale, rows_per_sample, dx,
+                 int(dx_dtype == BF16), dz, dgamma, dbeta, dbias, 0, M, D, ws, ws.numel())
+    else:
+        lib.call("getmi_layernorm_bwd", dy, x, mean, rstd, gamma, dres, rowscale, rows_per_sample, dx, dz, dgamma, dbeta,
+                 dbias, 0, M, D, ws, ws.numel())
     # (for this HBM-bound kernel the profile's second field is its ALGORITHMIC BYTES, not FLOPs: dy bf16 + x fp32 +
-    #  dx fp32 (+ dres fp32) (+ dz bf16) per element)
-    _prof_end(e0, "ln_bwd_kernel", float(M) * D * (2 + 4 + 4 + (4 if dres is not None else 0) + (2 if want_dz else 0)))
-    return dx, dz, dgamma, dbeta, dbias
+    #  dx (+ dres) in their stream type (+ dz bf16) per element)
+    sb = 2 if dx_dtype == BF16 else 4
+    rb = 0 if dres is None else (2 if res_b else 4)
+    _prof_end(e0, "ln_bwd_kernel", float(M) * D * (2 + 4 + sb + rb + (2 if dz is not None else 0)))
+    return dx, (dx if alias else dz), dgamma, dbeta, dbias
 
 
 def attention_fwd(qkv, B, T, H, scale, want_lo=False):

@@ -29,6 +29,8 @@ _SIGNATURES = {
     "getmi_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "getmi_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "getmi_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "getmi_layernorm_bwd_stream": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
+                                        _sz, _vp]),
     "getmi_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "getmi_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _vp]),

@@ -74,6 +74,16 @@ int getmi_layernorm_bwd(const void* dy_bf16, const float* x, const float* mean, 
                         float* dx, void* dz_bf16, float* dgamma, float* dbeta, float* dbias_prev, int accumulate,
                         int M, int D, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with the residual-gradient stream in bf16 on either side (autograd of `x + branch(LN(x))`,
+ * model/transformer.py:247-248, where PyTorch keeps that gradient in fp32): dres / dx are bf16 when the matching flag is
+ * non-zero, fp32 otherwise (both zero == getmi_layernorm_bwd).  With dx bf16 and rowscale null, dz may be null while
+ * dbias_prev is wanted: dz would equal dx bit for bit, so the caller uses dx.  12 instead of 16 bytes per element. */
+int getmi_layernorm_bwd_stream(const void* dy_bf16, const float* x, const float* mean, const float* rstd,
+                               const float* gamma, const void* dres, int dres_is_bf16, const float* rowscale,
+                               int rows_per_sample, void* dx, int dx_is_bf16, void* dz_bf16, float* dgamma, float* dbeta,
+                               float* dbias_prev, int accumulate, int M, int D, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- attention (model/transformer.py:58-96), packed qkv[B,T,3,H,64] bf16, head_dim 64 ---------- */
 /* out_lo (may be null): bf16(O - float(out)), what the bf16 rounding of the output dropped.  The backward forms
  * delta = rowsum(dO * O) from out + out_lo: with the rounded output alone every row of dS misses sum 0 by

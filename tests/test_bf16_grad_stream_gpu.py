@@ -1,0 +1,112 @@
+"""GPU: the bf16 gradient stream (GETMI_BF16_GRAD=1, functional._GradStream) -- the residual-stream
+gradient between blocks in bf16 (LayerNorm backward 12 instead of 16 bytes per element).  Off by default; this file
+switches it on and holds it to the SAME bars as the fp32 stream (tests/test_model_parity_gpu.py), plus the cases the side
+channel must not break: somebody watching a block output's gradient (the interpretation hooks of run.py:359-384) and a
+second consumer of a block's output."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import get_cpu as O
+from tests.golden_util import check_against_golden, golden_names, grouped, load_case
+from tests.test_model_parity_gpu import ATOL_GVAL, MIN_COS, RTOL_GNORM, RTOL_LOSS, RTOL_PRED, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_stream():
+    from get_model_amd import functional as Fn
+    old = Fn._BF16_GRAD
+    Fn._BF16_GRAD = True
+    yield Fn
+    Fn._BF16_GRAD = old
+    Fn.STREAM.slots.clear()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_bf16_gradient_stream_meets_the_fp32_stream_bars(name, bf16_stream):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = load_case(name)
+    loss, pred, grads = run_hip(c, c["train"])
+    assert not bf16_stream.STREAM.slots, "a stream slot was left behind"
+    check_against_golden(dict(c, name="bf16-stream " + name), loss.cpu(), pred.cpu(), grads, rtol_pred=RTOL_PRED,
+                         rtol_loss=RTOL_LOSS, rtol_gnorm=RTOL_GNORM, atol_gval_rel=ATOL_GVAL)
+    torch.set_num_threads(16)
+    _, _, ograds = O.loss_and_grads(c["kind"], c["sd"], c["batch"], num_layers=c["L"], keep_masks=c["keep"])
+    gg, og = grouped(grads), grouped(ograds)
+    worst = min((F.cosine_similarity(g, og[n], dim=0).item(), n) for n, g in gg.items())
+    print(f"MEASURED bf16-stream {name}: min gradient cosine {worst[0]:.6f} ({worst[1]})")
+    assert worst[0] >= MIN_COS, worst
+
+
+def _model(kind, L, sd):
+    from get_model_amd.config import build_model, region_model_yaml
+    m = build_model(region_model_yaml(kind, num_layers=L))
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+def test_watched_block_output_gets_its_real_gradient(bf16_stream):
+    """retain_grad on `encoder.blocks.1`'s output (what run.py:359-372 does): that tensor's .grad must be the real
+    gradient, not the zero placeholder autograd carries for unobserved tensors -- equal to the fp32-stream run's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L, B, N = 4, 2, 50
+    sd = O.fill_state_dict("finetune", seed=51, num_layers=L)
+    batch = {k: v.cuda() for k, v in O.make_batch(B, N, 61).items()}
+
+    def run():
+        m = _model("finetune", L, sd)
+        cap = {}
+
+        def hook(mod, inp, out):
+            out[0].retain_grad()
+            cap["t"] = out[0]
+
+        h = m.get_submodule("encoder.blocks.1").register_forward_hook(hook)
+        out = m(**m.get_input(batch))
+        pred, obs = m.before_loss(out, batch)
+        m.after_loss(m.loss(pred, obs)).backward()
+        h.remove()
+        return cap["t"].grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    g_b, pg_b = run()
+    bf16_stream._BF16_GRAD = False
+    g_f, pg_f = run()
+    assert g_b.abs().max().item() > 0
+    cos = F.cosine_similarity(g_b.flatten(), g_f.flatten(), dim=0).item()
+    print(f"MEASURED bf16-stream watched block output: cosine vs fp32 stream {cos:.6f}")
+    assert cos >= 0.9999
+    for n in pg_f:
+        c = F.cosine_similarity(pg_b[n].flatten(), pg_f[n].flatten(), dim=0).item()
+        assert c >= 0.9995, (n, c)
+
+
+def test_second_consumer_of_a_block_output_is_added_to_the_stream(bf16_stream):
+    """loss = model loss + a term on block 2's output: autograd sums the placeholder (zeros) and the extra term's
+    gradient; the block must add that to the bf16 gradient from the stream."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    L, B, N = 4, 2, 50
+    sd = O.fill_state_dict("finetune", seed=52, num_layers=L)
+    batch = {k: v.cuda() for k, v in O.make_batch(B, N, 62).items()}
+    w = O.hash_tensor((B, N + 1, 768), 63, -1e-3, 1e-3).cuda()
+
+    def run():
+        m = _model("finetune", L, sd)
+        cap = {}
+        h = m.get_submodule("encoder.blocks.2").register_forward_hook(lambda mod, i, o: cap.__setitem__("t", o[0]))
+        out = m(**m.get_input(batch))
+        pred, obs = m.before_loss(out, batch)
+        (m.after_loss(m.loss(pred, obs)) + (cap["t"] * w).sum()).backward()
+        h.remove()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    gb = run()
+    bf16_stream._BF16_GRAD = False
+    gf = run()
+    worst = min((F.cosine_similarity(gb[n].flatten(), gf[n].flatten(), dim=0).item(), n) for n in gf)
+    print(f"MEASURED bf16-stream second consumer: min cosine vs fp32 stream {worst[0]:.6f} ({worst[1]})")
+    assert worst[0] >= 0.9995, worst
