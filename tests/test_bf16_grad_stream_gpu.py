@@ -1,7 +1,7 @@
-"""GPU: the bf16 gradient stream (GETMI_BF16_GRAD=1, functional._GradStream) -- the residual-stream
-gradient between blocks in bf16 (LayerNorm backward 12 instead of 16 bytes per element).  Off by default; this file
-switches it on and holds it to the SAME bars as the fp32 stream (tests/test_model_parity_gpu.py), plus the cases the side
-channel must not break: somebody watching a block output's gradient (the interpretation hooks of run.py:359-384) and a
+"""GPU: the bf16 gradient stream (functional._GradStream) -- the residual-stream gradient between
+blocks in bf16 (LayerNorm backward 12 instead of 16 bytes per element; -0.57 ms per C2 step).  It met every bar of the
+fp32 stream at unchanged measured errors and is the default since round 3 (GETMI_BF16_GRAD=0 restores fp32).  This file
+holds BOTH settings to the same bars (tests/test_model_parity_gpu.py), plus the cases the side channel must not break: somebody watching a block output's gradient (the interpretation hooks of run.py:359-384) and a
 second consumer of a block's output."""
 import pytest
 import torch
@@ -14,30 +14,42 @@ from tests.test_model_parity_gpu import ATOL_GVAL, MIN_COS, RTOL_GNORM, RTOL_LOS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def bf16_stream():
+def _set_stream(on):
     from get_model_amd import functional as Fn
     old = Fn._BF16_GRAD
-    Fn._BF16_GRAD = True
+    Fn._BF16_GRAD = on
+    return Fn, old
+
+
+@pytest.fixture
+def bf16_stream():
+    Fn, old = _set_stream(True)
     yield Fn
     Fn._BF16_GRAD = old
     Fn.STREAM.slots.clear()
 
 
+@pytest.mark.parametrize("stream", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", golden_names())
-def test_bf16_gradient_stream_meets_the_fp32_stream_bars(name, bf16_stream):
+def test_bf16_gradient_stream_meets_the_fp32_stream_bars(name, stream):
+    """Both settings of the switch (bf16 is the default since round 3) against the golden vectors and the oracle at the
+    bars of tests/test_model_parity_gpu.py."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    c = load_case(name)
-    loss, pred, grads = run_hip(c, c["train"])
-    assert not bf16_stream.STREAM.slots, "a stream slot was left behind"
-    check_against_golden(dict(c, name="bf16-stream " + name), loss.cpu(), pred.cpu(), grads, rtol_pred=RTOL_PRED,
+    Fn, old = _set_stream(stream == "bf16")
+    try:
+        c = load_case(name)
+        loss, pred, grads = run_hip(c, c["train"])
+        assert not Fn.STREAM.slots, "a stream slot was left behind"
+    finally:
+        Fn._BF16_GRAD = old
+    check_against_golden(dict(c, name=f"{stream}-stream " + name), loss.cpu(), pred.cpu(), grads, rtol_pred=RTOL_PRED,
                          rtol_loss=RTOL_LOSS, rtol_gnorm=RTOL_GNORM, atol_gval_rel=ATOL_GVAL)
     torch.set_num_threads(16)
     _, _, ograds = O.loss_and_grads(c["kind"], c["sd"], c["batch"], num_layers=c["L"], keep_masks=c["keep"])
     gg, og = grouped(grads), grouped(ograds)
     worst = min((F.cosine_similarity(g, og[n], dim=0).item(), n) for n, g in gg.items())
-    print(f"MEASURED bf16-stream {name}: min gradient cosine {worst[0]:.6f} ({worst[1]})")
+    print(f"MEASURED {stream}-stream {name}: min gradient cosine {worst[0]:.6f} ({worst[1]})")
     assert worst[0] >= MIN_COS, worst
 
 

@@ -5,11 +5,11 @@ Tolerances (bf16 MFMA operands, fp32 accumulate / residual stream; SURVEY.md 5.9
 the worst value measured on MI355X over the seven fixtures (each test prints what it measured: `pytest -s`):
   prediction: max-abs error <= 2e-2 * max|pred|  (measured <= 9.4e-3, at 12 layers)
   loss      : 4.5e-3 relative                     (measured <= 2.1e-3)
-  gradients : per-parameter L2 norm within RTOL_GNORM, sampled elements within 6 % of the sample's max-abs (normalised
+  gradients : per-parameter L2 norm within 1.5 % (measured <= 6.3e-3), sampled elements within 6 % of the sample's max-abs (normalised
               max-abs; measured <= 3.9e-2, the q_bias cancellation sum of the 3-layer train case), cosine similarity of
               every full gradient tensor vs the oracle >= 0.9997 (measured >= 0.99989).
 """
-RTOL_PRED, RTOL_LOSS, RTOL_GNORM, ATOL_GVAL, MIN_COS = 2e-2, 4.5e-3, 4e-2, 6e-2, 0.9997
+RTOL_PRED, RTOL_LOSS, RTOL_GNORM, ATOL_GVAL, MIN_COS = 2e-2, 4.5e-3, 1.5e-2, 6e-2, 0.9997
 import pytest
 import torch
 import torch.nn.functional as F
