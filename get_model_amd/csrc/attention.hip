@@ -69,6 +69,8 @@ struct AttnFwdArgs {
     float* lse;
     int B, T, H;
     float scale;
+    const float* sample_scale;   // optional [B]: out = sample_scale[b] * softmax(QK^T)V (the DropPath factor of the attention
+                                 // branch folded into the saved output, functional.py); samples with factor 0 are skipped
 };
 
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
@@ -84,6 +86,22 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
     const bf16_t* base = p.qkv + (size_t)b * T * rs + h * HD;
     const int q0 = qb * 32 * nw + wave * 32;
     const int r = lane & 31, h2 = lane >> 5;
+    const float sb = p.sample_scale ? p.sample_scale[b] : 1.0f;      // workgroup-uniform
+    if (sb == 0.0f) {
+        // dropped sample (stochastic depth): its branch contributes nothing -- zero rows, no arithmetic, no barrier taken
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+            if (q0 + row < T) {
+                const size_t o = ((size_t)b * T + q0 + row) * (H * HD) + h * HD + ch * 8;
+                store_u4<kNtAttn>(p.out + o, z);
+                if (p.out_lo != nullptr) store_u4<kNtAttn>(p.out_lo + o, z);
+            }
+        }
+        if (h2 == 0 && q0 + r < T) p.lse[((size_t)b * H + h) * T + q0 + r] = 0.f;
+        return;
+    }
 
     bf16x8 qf[4];
     {
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
     const int q = q0 + r;
     // (the chunk loop ended with a barrier: the K/V buffers are free; each wave takes 4 KiB of them as its stage)
     if (q0 < T) {
-        const float inv = 1.0f / l;
+        const float inv = sb / l;
         char* blk = smem + wave * 4096;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -305,10 +323,41 @@ struct AttnBwdArgs {
     float* bias_partial;  // [2][B*nkb][H*64] fp32: per-workgroup column sums of dQ (k=0) and dV (k=1), or null
     int B, T, H;
     float scale;
+    const float* sample_scale;   // optional [B]: `out` (and out_lo) are sample_scale[b] * O and dout is the gradient w.r.t. THAT
+                                 // tensor (see AttnFwdArgs).  With s = sample_scale[b]: dO = s * dout, so delta = rowsum(dout * out)
+                                 // needs no factor, dP = s * dout.V^T; the kernels form P o (dout.V^T - delta / s) and multiply
+                                 // dQ, dK, dV and the bias sums by s at the end.  s == 0: the sample is skipped (zeros).
     int skew;             // diagnostic (GETMI_ATTN_SKEW): first-round workgroups start up to skew x 2048 cycles late.
                           // Measured: no effect at any spread (profiles/r02_attn_bwd_skew.txt), so the prologue is not an HBM
                           // burst of synchronised workgroups but the per-CU fetch limit (~10 B/clk from HBM)
 };
+
+// A sample whose DropPath factor is 0 (AttnBwdArgs::sample_scale): every gradient of this (b, h, key block) is zero.
+__device__ __forceinline__ void attn_bwd_zero(const AttnBwdArgs& p, int b, int h, int kbi, int nkb, int key_base, int key_count,
+                                              int tid) {
+    const int T = p.T, HH = p.H * HD;
+    const size_t rs = (size_t)3 * HH;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const float4 zf = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < T * 8; i += 512) {
+        const int q = i >> 3, ch = i & 7;
+        if (p.dq_acc == nullptr) {
+            store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + ch * 8, z);
+        } else {
+            float* d = p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + ch * 8;
+            store_f4<kNtAttn>(d, zf);
+            store_f4<kNtAttn>(d + 4, zf);
+        }
+    }
+    const int nkeys = max(0, min(key_count, T - key_base));
+    for (int i = tid; i < nkeys * 16; i += 512) {
+        const int which = i / (nkeys * 8), j = i - which * nkeys * 8;
+        const int key = key_base + (j >> 3), ch = j & 7;
+        store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + which) * HH + h * HD + ch * 8, z);
+    }
+    if (p.bias_partial != nullptr && tid < 128)
+        p.bias_partial[((size_t)(tid >> 6) * p.B * nkb + (size_t)b * nkb + kbi) * HH + h * HD + (tid & 63)] = 0.f;
+}
 
 // LDS map (bytes).  Everything a workgroup reads is staged ONCE per 256-query chunk (for T <= 256: once), so no
 // LDS-DMA is in flight inside the slice loop: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read that may
@@ -343,6 +392,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
     const float c2 = p.scale * LOG2E;
     const float inv_scale = 1.0f / p.scale;
     const int nks = min(8, (T - key_base + 31) >> 5);     // 32-key groups of this workgroup that hold a valid key
+    const float sb = p.sample_scale ? p.sample_scale[b] : 1.0f;      // workgroup-uniform (see AttnBwdArgs)
+    if (sb == 0.0f) {
+        attn_bwd_zero(p, b, h, kbi, nkb, key_base, 256, tid);
+        return;
+    }
+    const float osc = p.scale * sb, inv_sb = 1.0f / sb;
     STAMP(0);
     if (p.skew > 0 && blockIdx.x < 256) {
         const int n = (int)(((blockIdx.x * 97u) & 255u) * (unsigned)p.skew >> 8);
@@ -428,7 +483,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             acc += __shfl_xor(acc, 1, 64);
             // stored negated: they are the initial values of the S' / dP' accumulators
             if (tid & 1) stf[tid >> 1] = (qi < T) ? -lse[qi] * inv_scale : -INFINITY;
-            else stf[256 + (tid >> 1)] = -acc;
+            else stf[256 + (tid >> 1)] = -acc * inv_sb;
         }
         STAMP(2);
         __syncthreads();
@@ -549,13 +604,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                 const int d0 = dblk * 16 + (lane >> 4) * 4;
                 if (q < T) {
                     if (p.dq_acc == nullptr) {
-                        store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
+                        store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
                     } else {
                         // long context: this key block's partial dQ goes to its own fp32 slab (plain 16-byte
                         // stores; fp32 atomics measured 2.5 ms per call at T = 2001), summed by attn_dq_convert
                         float* dst = p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * (H * HD) + h * HD + d0;
-                        store_f4<kNtAttn>(dst, make_float4(acc[0] * p.scale, acc[1] * p.scale,
-                                                                      acc[2] * p.scale, acc[3] * p.scale));
+                        store_f4<kNtAttn>(dst, make_float4(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
                     }
                 }
             }
@@ -626,11 +680,12 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                 v = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[512 + w * 64 + d];
-                v *= p.scale;
+                v *= osc;
             } else {
                 v = 0.f;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
+                v *= sb;
             }
             const size_t R = (size_t)p.B * nkb;
             p.bias_partial[((size_t)(tid >> 6) * R + (size_t)b * nkb + kbi) * (H * HD) + h * HD + d] = v;
@@ -646,10 +701,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = db * 32 + 8 * g4 + 4 * h2;
-                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale,
-                                                    dk[db][4 * g4 + 2] * p.scale, dk[db][4 * g4 + 3] * p.scale));
-                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2],
-                                                         dv[db][4 * g4 + 3]));
+                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * osc, dk[db][4 * g4 + 1] * osc,
+                                                    dk[db][4 * g4 + 2] * osc, dk[db][4 * g4 + 3] * osc));
+                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4] * sb, dv[db][4 * g4 + 1] * sb, dv[db][4 * g4 + 2] * sb,
+                                                         dv[db][4 * g4 + 3] * sb));
             }
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -735,6 +790,12 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     const float inv_scale = 1.0f / p.scale;
     const int nks = min(7, (T - key_base + 31) >> 5);      // 32-key groups of this block with a valid key
     const int nsl = (T + 31) >> 5;                           // 32-query slices
+    const float sb = p.sample_scale ? p.sample_scale[b] : 1.0f;      // workgroup-uniform (see AttnBwdArgs)
+    if (sb == 0.0f) {
+        attn_bwd_zero(p, b, h, kbi, nkb, key_base, 224, tid);
+        return;
+    }
+    const float osc = p.scale * sb, inv_sb = 1.0f / sb;
     // Q / dO images and the constants table are rings of 8 slices (slot = slice & 7; for T <= 224 every slice has its own
     // slot), the O / O_lo stage a ring of 3: slice X is requested during slice X-3 and last read during slice X.
     const unsigned smem0 = lds_addr(smem);
@@ -795,9 +856,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         const int d0 = dblk * 16 + (ln >> 4) * 4;
         if (q < T) {
             if (p.dq_acc == nullptr)
-                store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
+                store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
             else      // several key blocks: this block's partial dQ goes to its own fp32 slab, summed by attn_dq_convert
-                store_f4<kNtAttn>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0, make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale));
+                store_f4<kNtAttn>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0, make_float4(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
         }
     };
 
@@ -877,7 +938,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             acc += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc), 0xB1, 0xf, 0xf, true));   // + the other half
             if ((wl & 1) == 0) {      // negated: they enter S' and dP'.  Rows past T: a finite stand-in for -inf, so that the
                                       // split stays finite and P underflows to exactly 0
-                const u32x2_t cl = bs_split3(X * 32 + d_lq < T ? -lv * inv_scale : -60000.f), cd = bs_split3(-acc);
+                const u32x2_t cl = bs_split3(X * 32 + d_lq < T ? -lv * inv_scale : -60000.f), cd = bs_split3(-acc * inv_sb);
                 bs_write_b128(smem0 + BS_STAT + ((X & 7) * 32 + d_lq) * 16, (u32x4_t){cl[0], cl[1], cd[0], cd[1]});
             }
         };
@@ -1131,10 +1192,11 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             if (tid < 64) {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[512 + w * 64 + d];
-                v *= p.scale;
+                v *= osc;
             } else {
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += red[w * 64 + d];
+                v *= sb;
             }
             p.bias_partial[((size_t)(tid >> 6) * p.B * nkb + (size_t)b * nkb + kbi) * HH + h * HD + d] = v;
         }
@@ -1147,10 +1209,10 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d0 = db * 32 + 8 * g4 + 4 * h2;
-                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * p.scale, dk[db][4 * g4 + 1] * p.scale,
-                                                    dk[db][4 * g4 + 2] * p.scale, dk[db][4 * g4 + 3] * p.scale));
-                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4], dv[db][4 * g4 + 1], dv[db][4 * g4 + 2],
-                                                         dv[db][4 * g4 + 3]));
+                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * osc, dk[db][4 * g4 + 1] * osc,
+                                                    dk[db][4 * g4 + 2] * osc, dk[db][4 * g4 + 3] * osc));
+                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4] * sb, dv[db][4 * g4 + 1] * sb, dv[db][4 * g4 + 2] * sb,
+                                                         dv[db][4 * g4 + 3] * sb));
             }
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -1182,11 +1244,11 @@ __global__ void attn_dq_convert_kernel(const float* __restrict__ acc, bf16_t* __
 
 // ------------------------------------------------------------------------------------------------
 int getmi_attn_fwd_impl(const bf16_t* qkv, bf16_t* out, bf16_t* out_lo, float* lse, int B, int T, int H, float scale,
-                        hipStream_t st) {
+                        const float* sample_scale, hipStream_t st) {
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_fwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "attn_fwd: pointers must be 16-byte aligned");
     GETMI_CHECK_ARG((uintptr_t)out_lo % 16 == 0, "attn_fwd: out_lo must be 16-byte aligned");
-    AttnFwdArgs a{qkv, out, out_lo, lse, B, T, H, scale};
+    AttnFwdArgs a{qkv, out, out_lo, lse, B, T, H, scale, sample_scale};
     // waves (= 32-query groups) per workgroup: 8 (256 queries: K/V of a (b, h) staged once for T <= 256, one staging
     // instruction per wave and chunk) unless 4 already cover T.  Measured at T = 201: 104 us vs 111 (4 waves) and 118
     // (7 waves: the staging no longer divides evenly); T = 2001: 366 vs 375.  GETMI_ATTN_FWD_WAVES overrides (4..8)
@@ -1229,8 +1291,8 @@ int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* 
                          hipStream_t st);
 
 int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_lo, const bf16_t* dout, const float* lse, bf16_t* dqkv,
-                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
-                        size_t workspace_bytes, hipStream_t st) {
+                        float* dq_bias, float* dv_bias, int B, int T, int H, float scale, const float* sample_scale,
+                        void* workspace, size_t workspace_bytes, hipStream_t st) {
     GETMI_CHECK_ARG(B > 0 && T > 0 && H > 0, "attn_bwd: bad shape B=%d T=%d H=%d", B, T, H);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_attn_bwd_workspace_bytes(B, T, H), "attn_bwd: workspace too small");
     GETMI_CHECK_ARG(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0) &&
@@ -1254,7 +1316,8 @@ int getmi_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* out_
         const char* e = getenv("GETMI_ATTN_SKEW");
         skew_env = e ? atoi(e) : -1;
     }
-    AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale, skew_env > 0 ? skew_env : 0};
+    AttnBwdArgs a{qkv, out, out_lo, dout, lse, dqkv, dq_acc, bias_partial, B, T, H, scale, sample_scale,
+                  skew_env > 0 ? skew_env : 0};
     if (attn_bwd_streamed())
         hipLaunchKernelGGL(attn_bwd_stream_kernel, dim3(B * H * nkb), dim3(512), BS_LDS, st, a);
     else

@@ -5,7 +5,7 @@
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; int M, N, K, lda, ldb; void* out0; void* out1; int ldo; const float* bias;
     const float* resid; const float* rowscale; int rows_per_sample; const bf16_t* aux; int ldaux;
-    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0;
+    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0; int prescaled;
 };
 int getmi_gemm_tn_colsum_rows(int M, int N);
 int getmi_gemm_tn_colsum_rows_max(int M, int N);
@@ -31,10 +31,10 @@ int getmi_ln_fwd_impl(const float*, const float*, const float*, bf16_t*, float*,
 size_t getmi_ln_bwd_workspace_bytes(int M, int D);
 int getmi_ln_bwd_impl(const bf16_t*, const float*, const float*, const float*, const float*, const void*, int, const float*,
                       int, void*, int, bf16_t*, float*, float*, float*, int, int, int, void*, size_t, hipStream_t);
-int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, bf16_t*, float*, int, int, int, float, hipStream_t);
+int getmi_attn_fwd_impl(const bf16_t*, bf16_t*, bf16_t*, float*, int, int, int, float, const float*, hipStream_t);
 size_t getmi_attn_bwd_workspace_bytes(int B, int T, int H);
 int getmi_attn_bwd_impl(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const float*, bf16_t*, float*, float*, int, int, int,
-                        float, void*, size_t, hipStream_t);
+                        float, const float*, void*, size_t, hipStream_t);
 int getmi_cast_pad_impl(const float*, bf16_t*, size_t, int, int, hipStream_t);
 int getmi_cast_transpose_impl(const float*, bf16_t*, int, int, hipStream_t);
 int getmi_qkv_bias_impl(const float*, const float*, float*, int, hipStream_t);
@@ -82,10 +82,10 @@ size_t getmi_gemm_tn_workspace_bytes(int M, int N) { return (size_t)getmi_gemm_t
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0, void* out1,
                   int ldo, const float* bias, const float* resid, const float* rowscale, int rows_per_sample,
                   const void* aux, int ldaux, const uint8_t* mask, const float* mask_token, int regions_per_sample,
-                  float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+                  float* dbias, void* workspace, size_t workspace_bytes, int flags, void* stream) {
     CuScope scope(false);      // tile choice, partial-row count and launch all see one CU budget
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
-               mask, mask_token, regions_per_sample, nullptr, 0};
+               mask, mask_token, regions_per_sample, nullptr, 0, (flags & 1) ? 1 : 0};
     if (dbias) {
         GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
         // partial rows for ANY tile height the launcher may pick (rows a variant does not write stay zero and add nothing)
@@ -134,15 +134,15 @@ int getmi_layernorm_bwd_stream(const void* dy, const float* x, const float* mean
                              ST(stream));
 }
 int getmi_attention_fwd(const void* qkv, void* out, void* out_lo, float* lse, int B, int T, int H, float scale,
-                        void* stream) {
-    return getmi_attn_fwd_impl(BF(qkv), BFW(out), BFW(out_lo), lse, B, T, H, scale, ST(stream));
+                        const float* sample_scale, void* stream) {
+    return getmi_attn_fwd_impl(BF(qkv), BFW(out), BFW(out_lo), lse, B, T, H, scale, sample_scale, ST(stream));
 }
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H) { return getmi_attn_bwd_workspace_bytes(B, T, H); }
 int getmi_attention_bwd(const void* qkv, const void* out, const void* out_lo, const void* dout, const float* lse,
-                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
-                        size_t workspace_bytes, void* stream) {
-    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(out_lo), BF(dout), lse, BFW(dqkv), dq_bias, dv_bias, B, T, H, scale, workspace,
-                               workspace_bytes, ST(stream));
+                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale,
+                        const float* sample_scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return getmi_attn_bwd_impl(BF(qkv), BF(out), BF(out_lo), BF(dout), lse, BFW(dqkv), dq_bias, dv_bias, B, T, H, scale,
+                               sample_scale, workspace, workspace_bytes, ST(stream));
 }
 int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream) {
     return getmi_fill_cls_impl(x0, cls_token, B, T, D, ST(stream));

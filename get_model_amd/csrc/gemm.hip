@@ -62,6 +62,8 @@ struct GemmArgs {
     int regions_per_sample;
     float* colsum;   // EPI_DGELU only: partial column sums of out0 (fp32, pre-rounding) [rows][N]; may be null
     int row0;        // first row of this launch within the caller's problem (split launches; only the row scale uses it)
+    int prescaled;   // EPI_BIAS_RESID: A already carries the row scale (DropPath fold, functional.py): out = resid + acc +
+                     // rowscale * bias instead of resid + rowscale * (acc + bias)
 };
 
 #define BM 128
@@ -102,10 +104,10 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 if (m < p.M && n < p.N) {
                     const f32x4 v = acc_get(mt, nt);
                     const float4 r = rv[mt][nt], b = bv[nt];
-                    const float s = sc[mt];
+                    const float s = sc[mt], sv = p.prescaled ? 1.0f : s;
                     *reinterpret_cast<float4*>((float*)p.out0 + (size_t)m * p.ldo + n) =
-                        make_float4(r.x + s * (v[0] + b.x), r.y + s * (v[1] + b.y), r.z + s * (v[2] + b.z),
-                                    r.w + s * (v[3] + b.w));
+                        make_float4(r.x + (sv * v[0] + s * b.x), r.y + (sv * v[1] + s * b.y), r.z + (sv * v[2] + s * b.z),
+                                    r.w + (sv * v[3] + s * b.w));
                 }
             }
         return;
@@ -169,6 +171,10 @@ __device__ __forceinline__ void epilogue_quads(const GemmArgs& p, Get acc_get, i
                 float h0, h1, h2, h3, g0, g1, g2, g3;
                 gelu_pair<EPI>(v[0], h0, g0); gelu_pair<EPI>(v[1], h1, g1);
                 gelu_pair<EPI>(v[2], h2, g2); gelu_pair<EPI>(v[3], h3, g3);
+                if (EPI == EPI_BIAS_GELUG && p.rowscale) {      // DropPath fold: both outputs carry the sample's factor
+                    const float s_ = p.rowscale[(m + p.row0) / p.rows_per_sample];
+                    h0 *= s_; h1 *= s_; h2 *= s_; h3 *= s_; g0 *= s_; g1 *= s_; g2 *= s_; g3 *= s_;
+                }
                 if (p.out0)      // NULL: inference, only gelu(u) is wanted
                     *reinterpret_cast<uint2*>((bf16_t*)p.out0 + (size_t)m * p.ldo + n) = pack4bf(h0, h1, h2, h3);
                 *reinterpret_cast<uint2*>((bf16_t*)p.out1 + (size_t)m * p.ldo + n) = pack4bf(g0, g1, g2, g3);
@@ -647,8 +653,8 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                         const int b = bp * 2 + bb;
                         const f32x4 v = acc[half * 4 + a][b];
                         const float4 bi = bv[b];
-                        const float s_ = sc[a];
-                        const f32x4 o = {s_ * (v[0] + bi.x), s_ * (v[1] + bi.y), s_ * (v[2] + bi.z), s_ * (v[3] + bi.w)};
+                        const float s_ = sc[a], sv_ = p.prescaled ? 1.0f : s_;
+                        const f32x4 o = {sv_ * v[0] + s_ * bi.x, sv_ * v[1] + s_ * bi.y, sv_ * v[2] + s_ * bi.z, sv_ * v[3] + s_ * bi.w};
                         qv[bb] = __builtin_bit_cast(u32x4, o);
                     }
                     // 16-B chunk index of (bb, c) is bb*4 + c
@@ -686,6 +692,9 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
         for (int a = 0; a < (half ? RB1 : 4); ++a) {
             const int ab = half * 4 + a;
             const bool mok = (em + ab * 16) < p.M;
+            float rsc = 1.0f;      // DropPath fold (training forward of fc1): both outputs carry the sample's factor
+            if (EPI == EPI_BIAS_GELUG && p.rowscale)
+                rsc = p.rowscale[(min(em + ab * 16, p.M - 1) + p.row0) / p.rows_per_sample];
             // bf16 output(s): 16 rows x 64 columns (128 B per row) per stage pass
             u32x2 qv[4], qg[4];
 #pragma unroll
@@ -703,6 +712,9 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                         float g0, g1, g2, g3;
                         gelu_pair<EPI>(d0, d0, g0); gelu_pair<EPI>(d1, d1, g1);
                         gelu_pair<EPI>(d2, d2, g2); gelu_pair<EPI>(d3, d3, g3);
+                        if (EPI == EPI_BIAS_GELUG && p.rowscale) {
+                            d0 *= rsc; d1 *= rsc; d2 *= rsc; d3 *= rsc; g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc;
+                        }
                         qg[b] = pack4bf_v(g0, g1, g2, g3);
                     }
                 }
@@ -1994,6 +2006,7 @@ int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
         case EPI_F32: return launch_gemm_tn<EPI_F32>(a, st);
         case EPI_BIAS_GELUG:
             GETMI_CHECK_ARG(a.out1 && a.bias, "gemm_tn: bias_gelu_grad needs out1 and bias");
+            GETMI_CHECK_ARG(!a.rowscale || a.rows_per_sample > 0, "gemm_tn: bias_gelu_grad row scale needs rows_per_sample");
             return launch_gemm_tn<EPI_BIAS_GELUG>(a, st);
         case EPI_DMUL:
             GETMI_CHECK_ARG(a.aux && a.ldaux % 4 == 0, "gemm_tn: dmul needs aux");

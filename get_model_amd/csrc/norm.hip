@@ -226,7 +226,8 @@ int getmi_ln_bwd_impl(const bf16_t* dy, const float* x, const float* mean, const
     GETMI_CHECK_ARG(D == 256 || D == 512 || D == 768 || D == 1024, "ln_bwd: D=%d unsupported", D);
     GETMI_CHECK_ARG(workspace_bytes >= getmi_ln_bwd_workspace_bytes(M, D), "ln_bwd: workspace too small");
     GETMI_CHECK_ARG(!rowscale || rows_per_sample > 0, "ln_bwd: rows_per_sample");
-    GETMI_CHECK_ARG(!dbias_prev || dz || (dx_bf16 && !rowscale), "ln_bwd: dbias_prev needs dz (or a bf16 dx without a row scale)");
+    // (dbias_prev without dz: the column sums of rowscale * dx are formed without storing that tensor -- the DropPath fold of
+    //  functional.py, whose GEMMs consume the unscaled bf16 dx)
     const int g = ln_grid(M);
     const int zsum = (dbias_prev != nullptr && dz == nullptr) ? 1 : 0;
     float* partial = reinterpret_cast<float*>(workspace);

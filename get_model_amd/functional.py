@@ -356,13 +356,21 @@ def concat_cls(x, cls_token):
 class EncoderBlock(torch.autograd.Function):
     """One pre-LN transformer block on the fp32 residual stream x[B,T,D].
 
-    scale1 / scale2: per-sample DropPath factors keep/keep_prob ([B] fp32) or None (identity)."""
+    scale1 / scale2: per-sample DropPath factors keep/keep_prob ([B] fp32) or None (identity).
+
+    Two modes, fixed at forward time (ctx.fold):
+      * fold (default, _BF16_GRAD): the DropPath factors are folded into the SAVED ACTIVATIONS -- the attention output is
+        stored as s1 * O, gelu(u) and gelu'(u) as s2 * gelu(u), s2 * gelu'(u) (and the residual GEMMs add
+        resid + acc + s * bias) -- so backward needs no scaled copy of the residual gradient: every GEMM consumes the
+        bf16 dx of the gradient stream itself, LayerNorm backward writes dx only (10 bytes per element instead of 16),
+        and attention skips dropped samples in both directions.  dx travels between blocks through STREAM (_GradStream).
+      * legacy (GETMI_BF16_GRAD=0): fp32 dx through autograd, dz = bf16(s * dx) handed over by _GradHandoff."""
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, qkv_w, q_bias, v_bias, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
                 scale1, scale2, num_heads, eps, up_block=False, up_scale=None):
         """up_block / up_scale: x is the output of another EncoderBlock whose fc2-branch DropPath factor was
-        up_scale (None = identity): this block's backward then also emits that block's dz2 (see _GradHandoff)."""
+        up_scale (None = identity): this block's backward then also emits what that block's backward starts from."""
         _need_gpu(x)
         B, T, D = x.shape
         M = B * T
@@ -370,6 +378,7 @@ class EncoderBlock(torch.autograd.Function):
         if D != H * 64:
             raise RuntimeError(f"get_model_amd attention kernel needs head_dim 64 (embed_dim {D}, heads {H})")
         dev = x.device
+        fold = _BF16_GRAD
         x2 = x.detach().reshape(M, D).contiguous()
         att_scale = 64 ** -0.5
         # --- attention branch ---
@@ -379,32 +388,35 @@ class EncoderBlock(torch.autograd.Function):
         # (the residual of the bf16 output is kept only when q_bias will get a gradient: see kernels.attention_fwd)
         needs_bwd = any(ctx.needs_input_grad)      # all False under no_grad / inference_mode
         a_lo = None
+        s_att = scale1 if fold else None           # fold: a = s1 * O, dropped samples skipped
         if needs_bwd and ctx.needs_input_grad[4] and _ATTN_LO:
-            a, lse, a_lo = K.attention_fwd(qkv, B, T, H, att_scale, want_lo=True)
+            a, lse, a_lo = K.attention_fwd(qkv, B, T, H, att_scale, want_lo=True, sample_scale=s_att)
         else:
-            a, lse = K.attention_fwd(qkv, B, T, H, att_scale)
+            a, lse = K.attention_fwd(qkv, B, T, H, att_scale, sample_scale=s_att)
         x_mid = torch.empty(M, D, dtype=torch.float32, device=dev)
         K.gemm_tn(K.EPI_BIAS_RESID, a, w_bf16(proj_w), x_mid, bias=proj_b.detach(), resid=x2, rowscale=scale1,
-                  rows_per_sample=T)
+                  rows_per_sample=T, prescaled=fold and scale1 is not None)
         # --- MLP branch ---
         h2, mean2, rstd2 = K.layernorm_fwd(x_mid, n2w.detach(), n2b.detach(), eps)
         Fh = fc1_w.shape[0]
         u = torch.empty(M, Fh, dtype=BF16, device=dev) if needs_bwd else None     # inference: gelu'(.) is not stored
         g = torch.empty(M, Fh, dtype=BF16, device=dev)
         # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply
-        K.gemm_tn(K.EPI_BIAS_GELUG, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach())
+        K.gemm_tn(K.EPI_BIAS_GELUG, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach(),
+                  rowscale=scale2 if fold else None, rows_per_sample=T)
         x_out = torch.empty(M, D, dtype=torch.float32, device=dev)
         K.gemm_tn(K.EPI_BIAS_RESID, g, w_bf16(fc2_w), x_out, bias=fc2_b.detach(), resid=x_mid, rowscale=scale2,
-                  rows_per_sample=T)
+                  rows_per_sample=T, prescaled=fold and scale2 is not None)
         ctx.save_for_backward(x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2,
                               n1w, n2w, a_lo)
         ctx.weights = (qkv_w, proj_w, fc1_w, fc2_w)
         ctx.dims = (B, T, D, H, att_scale)
         ctx.up = (bool(up_block), up_scale)
+        ctx.fold = fold
         out = x_out.view(B, T, D)
         ctx.gids = (None, None)
         ctx.x_ref = None
-        if _BF16_GRAD and needs_bwd:
+        if fold and needs_bwd:
             gid = STREAM.new_id()
             ctx.gids = (getattr(x, "_getmi_gid", None) if up_block else None, gid)
             ctx.x_ref = x if up_block else None         # looked at in backward: is anybody observing its gradient?
@@ -413,36 +425,99 @@ class EncoderBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx_out):
+        if ctx.fold:
+            return EncoderBlock._backward_fold(ctx, dx_out)
+        return EncoderBlock._backward_legacy(ctx, dx_out)
+
+    @staticmethod
+    def _backward_fold(ctx, dx_out):
         (x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2, n1w, n2w, a_lo) = ctx.saved_tensors
         qkv_w, proj_w, fc1_w, fc2_w = ctx.weights
         B, T, D, H, att_scale = ctx.dims
         M = B * T
         dev = dx_out.device
         need = ctx.needs_input_grad
-        side = _SideStream(dev)
         in_gid, out_gid = ctx.gids
+        # ---- the gradient of this block's output: bf16 from the stream, or whatever autograd delivered ----
         slot = STREAM.take(out_gid)
-        sdt = BF16 if _BF16_GRAD else torch.float32       # element type of the residual-gradient stream inside the block
+        dxb = dfc2_b = None
         if slot is not None:
-            # bf16 gradient stream: the consumer of this block's output left dx (bf16), dz2 and the fc2 bias gradient
-            dxb, sc_, dz2, dfc2_b = slot
+            sdx, sc_, _unused, sdb = slot
             same_scale = (sc_ is None and scale2 is None) or (sc_ is not None and scale2 is not None and
                                                                sc_.data_ptr() == scale2.data_ptr())
             if STREAM.is_placeholder(dx_out):
-                dx_out = dxb
-                if not same_scale:          # (cannot happen with GETTransformer's wiring; kept correct anyway)
-                    dx_out = dxb.float()
-                    dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
-            else:       # autograd delivered more than the placeholder (a hook, a second consumer of the block's
-                dx_out = dxb.float().add_(dx_out.reshape(M, D))       # output): add it; fp32 from here on
-                dz2, dfc2_b = K.scale_cast(dx_out, scale2, T)
+                if same_scale:
+                    dxb, dfc2_b = sdx, sdb
+                else:                       # (cannot happen with GETTransformer's wiring; kept correct anyway)
+                    dx_out = sdx.float()
+            else:       # autograd delivered more than the placeholder (a hook, a second consumer of the block's output)
+                dx_out = sdx.float().add_(dx_out.reshape(M, D))
+        if dxb is None:
+            full = dx_out.reshape(M, D).float().contiguous()
+            dxb, db0 = K.scale_cast(full, None, T)
+            dfc2_b = db0 if scale2 is None else K.scale_cast(full, scale2, T)[1]
+        # ---- MLP branch (g = s2 * gelu(u) and u = s2 * gelu'(u) carry the DropPath factor) ----
+        dfc2_w = K.gemm_wgrad(dxb, g, out=grad_buffer(fc2_w)) if need[12] else None
+        du = torch.empty_like(u)
+        dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
+        K.gemm_tn(K.EPI_DMUL, dxb, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)     # (dx @ W2) * s2 * gelu'(.), + column sums
+        dfc1_w = K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w)) if need[10] else None
+        dh2 = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
+        # dx_mid (bf16) only; the proj bias gradient = column sums of s1 * dx_mid, formed without storing that tensor
+        dx_mid, _, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dxb,
+                                                         rowscale=scale1, rows_per_sample=T, want_dz=False,
+                                                         want_dbias=True, dx_dtype=BF16)
+        # ---- attention branch (a = s1 * O) ----
+        da = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, dx_mid, w_bf16_t(proj_w), da)                    # dx_mid @ Wproj = gradient w.r.t. a
+        dq_bias = dv_bias = None
+        if need[4] or need[5]:
+            dqkv, dq_bias, dv_bias = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, want_bias=True, out_lo=a_lo,
+                                                     sample_scale=scale1)
         else:
-            dx_out = dx_out.reshape(M, D).contiguous()
-            # ---- MLP branch ----
-            # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
-            #  operand, so it waits only for the operand's producer and the two run side by side)
-            hit = HANDOFF.take(dx_out, scale2)
-            dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
+            dqkv = K.attention_bwd(qkv, a, da, lse, B, T, H, att_scale, sample_scale=scale1)
+        dproj_w = dqkv_w = None
+        if need[6] and need[3]:
+            dproj_w, dqkv_w = K.gemm_wgrad_pair(dx_mid, a, dqkv, h1, out_a=grad_buffer(proj_w), out_b=grad_buffer(qkv_w))
+        else:
+            if need[6]:
+                dproj_w = K.gemm_wgrad(dx_mid, a, out=grad_buffer(proj_w))
+            if need[3]:
+                dqkv_w = K.gemm_wgrad(dqkv, h1, out=grad_buffer(qkv_w))
+        dh1 = torch.empty(M, D, dtype=BF16, device=dev)
+        K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
+        up_block, up_scale = ctx.up
+        # the gradient handed to the block below: bf16 through STREAM when that block will take it and nobody is
+        # watching the tensor's gradient; else fp32 through autograd
+        to_stream = up_block and in_gid is not None and need[0] and not STREAM.observed(ctx.x_ref)
+        dx_in, _, dn1w, dn1b, dbias_up = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid,
+                                                         rowscale=up_scale if to_stream else None, rows_per_sample=T,
+                                                         want_dz=False, want_dbias=to_stream,
+                                                         dx_dtype=BF16 if to_stream else torch.float32)
+        if to_stream:
+            STREAM.put(in_gid, (dx_in, up_scale, None, dbias_up))
+            dx_ret = STREAM.placeholder((B, T, D), dev)
+        else:
+            dx_ret = dx_in.view(B, T, D)
+        return (dx_ret, dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
+                dfc1_b, dfc2_w, dfc2_b, None, None, None, None, None, None)
+
+    @staticmethod
+    def _backward_legacy(ctx, dx_out):
+        (x2, mean1, rstd1, h1, qkv, lse, a, x_mid, mean2, rstd2, h2, u, g, scale1, scale2, n1w, n2w, a_lo) = ctx.saved_tensors
+        qkv_w, proj_w, fc1_w, fc2_w = ctx.weights
+        B, T, D, H, att_scale = ctx.dims
+        M = B * T
+        dev = dx_out.device
+        need = ctx.needs_input_grad
+        dx_out = dx_out.reshape(M, D).contiguous()
+        side = _SideStream(dev)
+        # ---- MLP branch ----
+        # (each weight-gradient GEMM is issued on the side stream BEFORE the data-gradient GEMM that shares its
+        #  operand, so it waits only for the operand's producer and the two run side by side)
+        hit = HANDOFF.take(dx_out, scale2)
+        dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
         dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
         du = torch.empty_like(u)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
@@ -452,7 +527,7 @@ class EncoderBlock(torch.autograd.Function):
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
         dx_mid, dz1, dn2w, dn2b, dproj_b = K.layernorm_bwd(dh2, x_mid, mean2, rstd2, n2w.detach(), dres=dx_out,
                                                            rowscale=scale1, rows_per_sample=T, want_dz=True,
-                                                           want_dbias=True, dx_dtype=sdt)
+                                                           want_dbias=True)
         # ---- attention branch ----
         # (attn.proj's weight gradient has 9 output tiles: it shares a launch with attn.qkv's further down)
         pair = need[6] and need[3] and side.side is None
@@ -475,22 +550,13 @@ class EncoderBlock(torch.autograd.Function):
         dh1 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, dqkv, w_bf16_t(qkv_w), dh1)                      # dqkv @ Wqkv
         up_block, up_scale = ctx.up
-        # the gradient handed to the block below: bf16 through STREAM when that block will take it and nobody is
-        # watching the tensor's gradient; else fp32 through autograd (with the dz hand-off of _GradHandoff)
-        to_stream = _BF16_GRAD and up_block and in_gid is not None and need[0] and not STREAM.observed(ctx.x_ref)
         dx_in, dz_up, dn1w, dn1b, dbias_up = K.layernorm_bwd(dh1, x2, mean1, rstd1, n1w.detach(), dres=dx_mid,
                                                              rowscale=up_scale if up_block else None,
-                                                             rows_per_sample=T, want_dz=up_block, want_dbias=up_block,
-                                                             dx_dtype=BF16 if to_stream else torch.float32)
-        if to_stream:
-            STREAM.put(in_gid, (dx_in, up_scale, dz_up, dbias_up))
-            dx_ret = STREAM.placeholder((B, T, D), dev)
-        else:
-            if up_block:
-                HANDOFF.put(dx_in, up_scale, dz_up, dbias_up)
-            dx_ret = dx_in.view(B, T, D)
+                                                             rows_per_sample=T, want_dz=up_block, want_dbias=up_block)
+        if up_block:
+            HANDOFF.put(dx_in, up_scale, dz_up, dbias_up)
         side.join()
-        return (dx_ret, dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
+        return (dx_in.view(B, T, D), dn1w, dn1b, dqkv_w, dq_bias, dv_bias, dproj_w, dproj_b, dn2w, dn2b, dfc1_w,
                 dfc1_b, dfc2_w, dfc2_b, None, None, None, None, None, None)
 
 
@@ -507,7 +573,8 @@ class FinalNorm(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, w)
         ctx.dims = (B, T, D)
         ctx.up = (bool(up_block), up_scale)      # as in EncoderBlock.forward
-        ctx.in_gid = getattr(x, "_getmi_gid", None) if (_BF16_GRAD and up_block) else None
+        ctx.fold = _BF16_GRAD
+        ctx.in_gid = getattr(x, "_getmi_gid", None) if (ctx.fold and up_block) else None
         ctx.x_ref = x if ctx.in_gid is not None else None
         return y.view(B, T, D)
 
@@ -519,14 +586,19 @@ class FinalNorm(torch.autograd.Function):
         if dy.dtype != BF16:
             dy = dy.to(BF16)
         up_block, up_scale = ctx.up
-        to_stream = ctx.in_gid is not None and ctx.needs_input_grad[0] and not STREAM.observed(ctx.x_ref)
+        if ctx.fold:        # see _GradStream / EncoderBlock._backward_fold
+            to_stream = ctx.in_gid is not None and ctx.needs_input_grad[0] and not STREAM.observed(ctx.x_ref)
+            dx, _, dw, db, dbias_up = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach(),
+                                                      rowscale=up_scale if to_stream else None, rows_per_sample=T,
+                                                      want_dz=False, want_dbias=to_stream,
+                                                      dx_dtype=BF16 if to_stream else torch.float32)
+            if to_stream:
+                STREAM.put(ctx.in_gid, (dx, up_scale, None, dbias_up))
+                return STREAM.placeholder((B, T, D), dy.device), dw, db, None, None, None
+            return dx.view(B, T, D), dw, db, None, None, None
         dx, dz_up, dw, db, dbias_up = K.layernorm_bwd(dy.contiguous(), x2, mean, rstd, w.detach(),
                                                       rowscale=up_scale if up_block else None, rows_per_sample=T,
-                                                      want_dz=up_block, want_dbias=up_block,
-                                                      dx_dtype=BF16 if to_stream else torch.float32)
-        if to_stream:       # see _GradStream
-            STREAM.put(ctx.in_gid, (dx, up_scale, dz_up, dbias_up))
-            return STREAM.placeholder((B, T, D), dy.device), dw, db, None, None, None
+                                                      want_dz=up_block, want_dbias=up_block)
         if up_block:
             HANDOFF.put(dx, up_scale, dz_up, dbias_up)
         return dx.view(B, T, D), dw, db, None, None, None

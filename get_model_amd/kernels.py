@@ -83,7 +83,7 @@ def qkv_bias(q_bias, v_bias):
 
 
 def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, rows_per_sample=0, aux=None,
-            mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None):
+            mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None, prescaled=False):
     """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated (out0 may be None for the
     two-output GELU epilogues: only gelu(u) is stored)."""
     _chk(A, B, out0, out1, bias, resid, rowscale, aux, mask, mask_token)
@@ -96,7 +96,7 @@ def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, ro
     ldo = (out0 if out0 is not None else out1).shape[-1]
     lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, ldo, bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
-             regions_per_sample, dbias, ws, 0 if ws is None else ws.numel())
+             regions_per_sample, dbias, ws, 0 if ws is None else ws.numel(), 1 if prescaled else 0)
     _prof_end(e0, "gemm_tn_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K)
     return out0
 
@@ -180,28 +180,29 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, rowscale=None, rows_per_s
     return dx, (dx if alias else dz), dgamma, dbeta, dbias
 
 
-def attention_fwd(qkv, B, T, H, scale, want_lo=False):
+def attention_fwd(qkv, B, T, H, scale, want_lo=False, sample_scale=None):
     """qkv bf16 [B*T, 3*H*64] (packed [B,T,3,H,64]) -> (out bf16 [B*T, H*64], lse fp32 [B,H,T]); with want_lo also
     the rounding residual bf16(O - out) that attention_bwd takes as out_lo."""
-    _chk(qkv)
+    _chk(qkv, sample_scale)
     out = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device)
     lo = torch.empty(B * T, H * 64, dtype=BF16, device=qkv.device) if want_lo else None
     lse = torch.empty(B, H, T, dtype=F32, device=qkv.device)
     e0 = _prof_begin("attn_fwd_kernel")
-    lib.call("getmi_attention_fwd", qkv, out, lo, lse, B, T, H, float(scale))
+    lib.call("getmi_attention_fwd", qkv, out, lo, lse, B, T, H, float(scale), sample_scale)
     _prof_end(e0, "attn_fwd_kernel", 4.0 * B * H * T * T * 64)
     return (out, lse, lo) if want_lo else (out, lse)
 
 
-def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False, out_lo=None):
+def attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=False, out_lo=None, sample_scale=None):
     """-> dqkv, or (dqkv, dq_bias [H*64], dv_bias [H*64]) with want_bias (column sums of the Q / V thirds, fp32)."""
-    _chk(qkv, out, dout, lse, out_lo)
+    _chk(qkv, out, dout, lse, out_lo, sample_scale)
     dqkv = torch.empty_like(qkv)
     dqb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     dvb = torch.empty(H * 64, dtype=F32, device=qkv.device) if want_bias else None
     ws = _ws(lib.query("getmi_attention_bwd_workspace_bytes", B, T, H), qkv.device)
     e0 = _prof_begin("attn_bwd_kernel(+delta)")
-    lib.call("getmi_attention_bwd", qkv, out, out_lo, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), ws, ws.numel())
+    lib.call("getmi_attention_bwd", qkv, out, out_lo, dout, lse, dqkv, dqb, dvb, B, T, H, float(scale), sample_scale, ws,
+             ws.numel())
     _prof_end(e0, "attn_bwd_kernel(+delta)", 10.0 * B * H * T * T * 64)
     return (dqkv, dqb, dvb) if want_bias else dqkv
 

@@ -22,7 +22,7 @@ _SIGNATURES = {
     "getmi_cast_transpose_f32_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "getmi_qkv_bias": (_i, [_vp, _vp, _vp, _i, _vp]),
     "getmi_gemm_tn": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp,
-                           _sz, _vp]),
+                           _sz, _i, _vp]),
     "getmi_gemm_tn_workspace_bytes": (_sz, [_i, _i]),
     "getmi_gemm_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
@@ -31,9 +31,9 @@ _SIGNATURES = {
     "getmi_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "getmi_layernorm_bwd_stream": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp,
                                         _sz, _vp]),
-    "getmi_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "getmi_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "getmi_attention_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "getmi_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "getmi_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "getmi_fill_cls": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "getmi_embed_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_embed_bwd_prep": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

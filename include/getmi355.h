@@ -55,7 +55,11 @@ int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, 
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0,
                   void* out1, int ldo, const float* bias, const float* resid, const float* rowscale,
                   int rows_per_sample, const void* aux, int ldaux, const uint8_t* mask, const float* mask_token,
-                  int regions_per_sample, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+                  int regions_per_sample, float* dbias, void* workspace, size_t workspace_bytes, int flags,
+                  void* stream);
+/* rowscale with epilogue 6: both outputs are multiplied by rowscale[row/rows_per_sample] (the DropPath factor of
+ * transformer.py:248 folded into the saved activations, so that no scaled copy of the gradient is needed in backward).
+ * flags bit 0 with epilogue 2: the A operand already carries that factor: out0 = resid + acc + rowscale*bias. */
 /* DGELU / DMUL only: dbias[N] (optional) = column sums of out0 before rounding = bias gradient of the Linear whose
  * pre-activation (or its GELU derivative) is `aux` (fc1.bias); needs workspace of getmi_gemm_tn_workspace_bytes(M, N). */
 size_t getmi_gemm_tn_workspace_bytes(int M, int N);
@@ -88,16 +92,20 @@ int getmi_layernorm_bwd_stream(const void* dy_bf16, const float* x, const float*
 /* out_lo (may be null): bf16(O - float(out)), what the bf16 rounding of the output dropped.  The backward forms
  * delta = rowsum(dO * O) from out + out_lo: with the rounded output alone every row of dS misses sum 0 by
  * dO.(O - bf16(O)), which only the q_bias gradient (a cancellation sum over all of dS) can see. */
+/* sample_scale (may be null): [B] fp32, the per-sample DropPath factor of the attention branch (keep / keep_prob,
+ * model/transformer.py:247) folded into the output: out = sample_scale[b] * softmax(QK^T)V, and samples whose factor is 0
+ * are skipped (zero rows) in forward and backward.  getmi_attention_bwd then takes `out` as produced and dout = the
+ * gradient w.r.t. that scaled output. */
 int getmi_attention_fwd(const void* qkv, void* out, void* out_lo, float* lse, int B, int T, int H, float scale,
-                        void* stream);
+                        const float* sample_scale, void* stream);
 size_t getmi_attention_bwd_workspace_bytes(int B, int T, int H);
 /* dq_bias / dv_bias (each [H*64] fp32, may be null): the gradients of Attention.q_bias / v_bias
  * (model/transformer.py:52-57) = column sums over all tokens of the Q and V thirds of d(qkv), taken in fp32
  * (dq_bias = scale * sum_key (sum_q dS[q][key]) K[key] from the fp32 dS; dv_bias from the dV accumulators).
  * out_lo: the forward's residual output, or null. */
 int getmi_attention_bwd(const void* qkv, const void* out, const void* out_lo, const void* dout, const float* lse,
-                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        void* dqkv, float* dq_bias, float* dv_bias, int B, int T, int H, float scale,
+                        const float* sample_scale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- region embed glue (model/model.py:520-525,571-573) ---------------------------------------- */
 int getmi_fill_cls(float* x0, const float* cls_token, int B, int T, int D, void* stream);

@@ -461,3 +461,130 @@ def test_staged_attention_backward_stays_correct():
                         "-m", "gpu", "-k", "test_attention", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-1000:])
+
+
+# ---- DropPath fold (round 3): the per-sample factor lives in the saved activations --------------------------------
+@pytest.mark.parametrize("B,T,H", [(4, 201, 3), (3, 37, 2), (3, 300, 1)])
+@pytest.mark.parametrize("stream_env", ["1", "0"])
+def test_attention_with_sample_scale(K, B, T, H, stream_env, monkeypatch):
+    """out = s_b * Attn(q, k, v) with s_b in {0, 1/keep}: forward rows, the residual, and the backward given
+    dout = dL/d(out) against autograd of the same expression; samples with s_b = 0 give exact zeros everywhere."""
+    scale = 0.125
+    qkv = bf(rnd(B * T, 3 * H * 64, scale=1.5, seed=41))
+    sc = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.9][:B], device="cuda")
+    out, lse, lo = K.attention_fwd(qkv, B, T, H, scale, want_lo=True, sample_scale=sc)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, _ = attn_ref(qr, B, T, H, scale)
+    ref = o_ref * sc.repeat_interleave(T).unsqueeze(1)
+    close(out.float() + lo.float(), ref, 8e-3, 4e-3, "attn.out(scaled)")
+    assert (out.view(B, T, -1)[1] == 0).all() and (lo.view(B, T, -1)[1] == 0).all()
+    dout = bf(rnd(B * T, H * 64, seed=42))
+    ref.backward(dout.float())
+    g = qr.grad
+    dqkv, dqb, dvb = K.attention_bwd(qkv, out, dout, lse, B, T, H, scale, want_bias=True, out_lo=lo, sample_scale=sc)
+    assert (dqkv.view(B, T, -1)[1] == 0).all()
+    err = (dqkv.float() - g).abs().max().item()
+    assert err <= 1.5e-2 * g.abs().max().item(), f"attn.dqkv(scaled) err {err:.3e}"
+    assert F.cosine_similarity(dqkv.float().flatten(), g.flatten(), dim=0).item() > 0.9995
+    D = H * 64
+    for name, got, third, rel in (("dq_bias", dqb, g[:, :D], 1e-3), ("dv_bias", dvb, g[:, 2 * D:], 4e-3)):
+        tol = rel * third.abs().sum(0).max().item()
+        e = (got - third.sum(0)).abs().max().item()
+        assert e <= tol, f"attn.{name}(scaled) err {e:.3e} > {tol:.3e}"
+
+
+def test_staged_attention_backward_with_sample_scale():
+    """The same through the staged backward kernel (GETMI_ATTN_STREAM=0 is read once per process: a subprocess)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import torch, torch.nn.functional as F
+from get_model_amd import kernels as K
+B, T, H = 3, 201, 2
+g = torch.Generator(device="cpu").manual_seed(7)
+qkv = (torch.randn(B * T, 3 * H * 64, generator=g) * 1.5).cuda().bfloat16()
+dout = torch.randn(B * T, H * 64, generator=g).cuda().bfloat16()
+sc = torch.tensor([1.25, 0.0, 1.25], device="cuda")
+out, lse, lo = K.attention_fwd(qkv, B, T, H, 0.125, want_lo=True, sample_scale=sc)
+qr = qkv.float().requires_grad_(True)
+q, k, v = qr.view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+o = (((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * T, H * 64)
+(o * sc.repeat_interleave(T).unsqueeze(1)).backward(dout.float())
+dqkv, dqb, dvb = K.attention_bwd(qkv, out, dout, lse, B, T, H, 0.125, want_bias=True, out_lo=lo, sample_scale=sc)
+gr = qr.grad
+assert (dqkv.view(B, T, -1)[1] == 0).all()
+assert (dqkv.float() - gr).abs().max().item() <= 1.5e-2 * gr.abs().max().item()
+assert F.cosine_similarity(dqkv.float().flatten(), gr.flatten(), dim=0).item() > 0.9995
+D = H * 64
+assert (dvb - gr[:, 2 * D:].sum(0)).abs().max().item() <= 4e-3 * gr[:, 2 * D:].abs().sum(0).max().item()
+assert (dqb - gr[:, :D].sum(0)).abs().max().item() <= 1e-3 * gr[:, :D].abs().sum(0).max().item()
+print("OK")
+"""
+    env = dict(os.environ, GETMI_ATTN_STREAM="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("M,T", [(804, 201), (4020, 201), (300, 37)])
+def test_gemm_epilogues_with_folded_row_scale(K, M, T):
+    """Epilogue 6 with a row scale (both outputs x s_b) and epilogue 2 with the `prescaled` flag
+    (out = resid + acc + s_b * bias), small-tile and 256 x 256 persistent kernels (M >= 2048)."""
+    D, Fh = 768, 3072
+    Bn = M // T
+    sc = ((torch.arange(Bn) % 3 != 1).float() / 0.9).cuda()
+    srow = sc.repeat_interleave(T).unsqueeze(1)
+    x = bf(rnd(M, D, seed=51))
+    w1 = bf(rnd(Fh, D, scale=0.05, seed=52))
+    b1 = rnd(Fh, scale=0.1, seed=53)
+    u = torch.empty(M, Fh, dtype=torch.bfloat16, device="cuda")
+    g = torch.empty_like(u)
+    K.gemm_tn(K.EPI_BIAS_GELUG, x, w1, u, out1=g, bias=b1, rowscale=sc, rows_per_sample=T)
+    pre = (x.float() @ w1.float().t() + b1).requires_grad_(True)
+    gref = F.gelu(pre)
+    gref.sum().backward()
+    close(g, gref * srow, 8e-3, 2e-3, "geluG.g(scaled)")
+    close(u, pre.grad * srow, 8e-3, 2e-3, "geluG.g'(scaled)")
+    # the same call without out0 (inference) stores the same g
+    g2 = torch.empty_like(g)
+    K.gemm_tn(K.EPI_BIAS_GELUG, x, w1, None, out1=g2, bias=b1, rowscale=sc, rows_per_sample=T)
+    assert torch.equal(g2, g)
+    # residual epilogue: A already carries the factor
+    w2 = bf(rnd(D, Fh, scale=0.03, seed=54))
+    b2 = rnd(D, scale=0.1, seed=55)
+    resid = rnd(M, D, seed=56)
+    out = torch.empty(M, D, device="cuda")
+    K.gemm_tn(K.EPI_BIAS_RESID, g, w2, out, bias=b2, resid=resid, rowscale=sc, rows_per_sample=T, prescaled=True)
+    ref = resid + g.float() @ w2.float().t() + srow * b2
+    close(out, ref, 2e-3, 2e-3, "resid(prescaled)")
+    out2 = torch.empty(M, D, device="cuda")
+    K.gemm_tn(K.EPI_BIAS_RESID, g, w2, out2, bias=b2, resid=resid, rowscale=sc, rows_per_sample=T)
+    close(out2, resid + srow * (g.float() @ w2.float().t() + b2), 2e-3, 2e-3, "resid(unfolded)")
+
+
+def test_layernorm_bwd_bias_sums_without_the_scaled_copy(K):
+    """bf16 stream forms: dres / dx in bf16, and dbias_prev = column sums of rowscale * dx WITHOUT a dz output."""
+    M, D, T = 603, 768, 201
+    x = rnd(M, D, seed=61)
+    gamma = rnd(D, scale=0.2, seed=62) + 1.0
+    beta = rnd(D, scale=0.1, seed=63)
+    y, mean, rstd = K.layernorm_fwd(x, gamma, beta)
+    dy = bf(rnd(M, D, seed=64))
+    dres = bf(rnd(M, D, seed=65))
+    sc = torch.tensor([1.25, 0.0, 1.25], device="cuda")
+    dx, dz, dg, dbt, dbias = K.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, rowscale=sc, rows_per_sample=T,
+                                             want_dz=False, want_dbias=True, dx_dtype=torch.bfloat16)
+    assert dz is None and dx.dtype == torch.bfloat16
+    dx_f, dz_f, dg_f, dbt_f, dbias_f = K.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres.float(), rowscale=sc,
+                                                       rows_per_sample=T, want_dz=True, want_dbias=True)
+    close(dx, dx_f, 4e-3, 1e-4, "ln.dx(bf16 stream)")
+    close(dbias, dbias_f, 1e-4, 1e-3, "ln.dbias(no dz)")
+    close(dg, dg_f, 1e-5, 1e-4, "ln.dgamma")
+    # no row scale + bf16 dx: dz is dx itself
+    dx2, dz2, _, _, db2 = K.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, want_dz=True, want_dbias=True,
+                                          dx_dtype=torch.bfloat16)
+    assert dz2 is dx2
+    close(db2, dx2.float().sum(0), 1e-3, 2e-2, "ln.dbias(alias)")
