@@ -320,12 +320,23 @@ __device__ __forceinline__ void phase_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Rows of an 8-wave output tile.  RB1 = 2 / 3 / 4: both wave rows own 64 + 16 * RB1 rows (192 / 224 / 256-row tiles).
+// RB1 = 5 (round 3, persistent kernel only): the ASYMMETRIC 208-row tile -- wave row 0 owns 64 + 48 rows, wave row 1
+// 64 + 32 -- for N = 768 at M = 51 456: 248 x 3 = 744 tiles = 2.9 rounds of 256 CUs, every CU busy in all three, where
+// 224-row tiles (690) leave 30 % of the CUs idle in the third round.  The two waves that share a SIMD are one of each
+// wave row, so the matrix pipes stay balanced.
+template <int RB1> struct TileRows {
+    static constexpr int rb0 = RB1 == 5 ? 3 : RB1, rb1 = RB1 == 5 ? 2 : RB1;      // real 16-row blocks of the second half
+    static constexpr int hw0 = 64 + 16 * rb0, hw1 = 64 + 16 * rb1, bm = hw0 + hw1;
+    static constexpr int rbmax = rb0, rbmin = rb1;
+};
+
 // (defined with the persistent kernel below; the one-tile kernel uses them for its fp32 residual epilogue)
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ u32x4 make_rsrc(const void* ptr, unsigned bytes);
 template <int EPI, int RB1>
 __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4], int m0w, int n0w, int prow, u32x4 rs0,
-                                           u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage);
+                                           u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage, int row_end);
 
 // RB1 = 16-row blocks of each wave's SECOND 64-row half that are real output (4: 256-row tile, 3: 224-row tile).
 // The 224-row tile exists for tile quantisation only: M = 51 456, N = 768 is 603 tiles of 256 rows = 2.36 rounds on
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(GemmArgs p) {
         __syncthreads();
         const u32x4 rs0 = make_rsrc(p.out0, (unsigned)((size_t)p.M * p.ldo * 4));
         const float* bl = p.bias != nullptr ? bias_img + wn * 64 + (lane >> 4) * 4 : nullptr;
-        epilogue_p<EPI, RB1>(p, acc, m0 + wm * HW, n0 + wn * 64, tm * 4 + wm * 2, rs0, rs0, rs0, bl, smem + 1024 + wave * 2048);
+        epilogue_p<EPI, RB1>(p, acc, m0 + wm * HW, n0 + wn * 64, tm * 4 + wm * 2, rs0, rs0, rs0, bl, smem + 1024 + wave * 2048, p.M);
         return;
     }
     const int em = m0 + wm * HW + (lane & 15);
@@ -544,7 +555,7 @@ __device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
 
 template <int EPI, int RB1>
 struct EpiStores {   // buffer-store instructions per wave and output tile (EXACT: used in the counted waits)
-    static constexpr int value = ((EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 4 : 2) * (4 + RB1);
+    static constexpr int value = ((EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 4 : 2) * (4 + TileRows<RB1>::rbmax);
 };
 
 // wait until at most 2*halftiles (+ EXTRA) vector-memory operations of this wave are outstanding
@@ -591,7 +602,11 @@ __device__ __forceinline__ void stage_w128x2_r128x2(unsigned wa, unsigned ra, u3
 // writes at most 2-way conflicted.  m0w / n0w: first row / column of the wave's block.
 template <int EPI, int RB1>
 __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4], int m0w, int n0w, int prow,
-                                           u32x4 rs0, u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage) {
+                                           u32x4 rs0, u32x4 rs1, u32x4 rsc, const float* bias_lds, char* stage,
+                                           int row_end) {
+    // row_end: first row this wave must NOT store (<= p.M; the asymmetric tile's wave row 1 runs the loops of wave row 0
+    // -- the store count every counted wait relies on is the same for all waves -- and drops its phantom row block here)
+    constexpr int RBX = TileRows<RB1>::rbmax;
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, c = lane >> 4;
     const int rrow = lane >> 3, rch = lane & 7;          // read-back: 8 rows x 8 chunks per pass
@@ -644,7 +659,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                     }
             }
 #pragma unroll
-            for (int a = 0; a < (half ? RB1 : 4); ++a)
+            for (int a = 0; a < (half ? RBX : 4); ++a)
 #pragma unroll
                 for (int bp = 0; bp < 2; ++bp) {
                     u32x4 qv[2], dd[2];
@@ -663,7 +678,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                     for (int ps = 0; ps < 2; ++ps) {
                         const int row = ps * 8 + rrow;
                         const int m = m0w + (half * 4 + a) * 16 + row, n = n0w + bp * 32 + rch * 4;
-                        const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 4) : OOB_OFF;
+                        const unsigned off = (m < row_end && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 4) : OOB_OFF;
                         const f32x4 t = __builtin_bit_cast(f32x4, dd[ps]);
                         const float4 q = rv[a][bp][ps];
                         const f32x4 o = {q.x + t[0], q.y + t[1], q.z + t[2], q.w + t[3]};
@@ -689,9 +704,9 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                                                                 min(en + b * 16, p.N - 4));
         }
 #pragma unroll
-        for (int a = 0; a < (half ? RB1 : 4); ++a) {
+        for (int a = 0; a < (half ? RBX : 4); ++a) {
             const int ab = half * 4 + a;
-            const bool mok = (em + ab * 16) < p.M;
+            const bool mok = (em + ab * 16) < row_end;
             float rsc = 1.0f;      // DropPath fold (training forward of fc1): both outputs carry the sample's factor
             if (EPI == EPI_BIAS_GELUG && p.rowscale)
                 rsc = p.rowscale[(min(em + ab * 16, p.M - 1) + p.row0) / p.rows_per_sample];
@@ -734,7 +749,7 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
                 for (int ps = 0; ps < 2; ++ps) {
                     const int row = ps * 8 + rrow;
                     const int m = m0w + ab * 16 + row, n = n0w + rch * 8;
-                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 2) : OOB_OFF;
+                    const unsigned off = (m < row_end && n < p.N) ? (unsigned)(((size_t)m * p.ldo + n) * 2) : OOB_OFF;
                     st_b128<EpiNt<EPI>::value>(dd[ps], off, outp == 0 ? rs0 : rs1);
                 }
             }
@@ -795,10 +810,13 @@ template <int EPI, int RB1>      // RB1: see gemm_tn256_kernel (4 = 256-row tile
 __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int ntiles, int group_n, int skew) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int E = EpiStores<EPI, RB1>::value;
-    constexpr int BMv = 128 + 32 * RB1, HW = BMv / 2;
+    typedef TileRows<RB1> TR;
+    constexpr int BMv = TR::bm, HW0 = TR::hw0;                   // tile rows, first row of wave row 1
+    constexpr int RBMIN = TR::rbmin, RBMAX = TR::rbmax;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    const bool rb_hi = wm == 0;                                  // this wave owns RBMAX blocks in its second half (wave-uniform)
     const int G = gridDim.x;
     const int bslot = xcd_remap(blockIdx.x, G);
     const int tiles_n = (p.N + 255) >> 8;
@@ -830,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
                 const int hr = (wave * 2 + jj) * 8 + (lane >> 3);
                 if (j == 0 || j == 3) {
                     const int row = ((hr >> 6) << 7) + (j == 3) * 64 + (hr & 63);
-                    const int g = min(tm * BMv + (hr >> 6) * HW + (j == 3) * 64 + (hr & 63), p.M - 1);
+                    const int g = min(tm * BMv + ((hr >> 6) ? HW0 : 0) + (j == 3) * 64 + (hr & 63), p.M - 1);
                     o[j][jj] = (unsigned)((size_t)g * p.lda * 2) + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
                 } else {
                     const int row = ((hr >> 5) << 6) + (j - 1) * 32 + (hr & 31);
@@ -919,12 +937,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     GP_RD(fa[2][ks], addr, (MH)*8192 + 4096); GP_RD(fa[3][ks], addr, (MH)*8192 + 6144);
 #define GP_RD_B(FB, NH, ks, addr) GP_RD(FB[0][ks], addr, (NH)*4096); GP_RD(FB[1][ks], addr, (NH)*4096 + 2048);
     // the two MFMAs of row-block mt, k-step ks of quadrant (MH, NH)
-#define GP_MM(MH, NH, FB, mt, ks)                                                                          \
-    if constexpr ((MH) == 0 || (mt) < RB1) {                                                               \
+#define GP_MM2(MH, NH, FB, mt, ks)                                                                         \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                   \
             acc[(MH)*4 + mt][(NH)*2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
                 __builtin_bit_cast(bf16x8, FB[nt][ks]), __builtin_bit_cast(bf16x8, fa[mt][ks]),           \
-                acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);                                                   \
+                acc[(MH)*4 + mt][(NH)*2 + nt], 0, 0, 0);
+#define GP_MM(MH, NH, FB, mt, ks)                                                                          \
+    if constexpr ((MH) == 0 || (mt) < RBMIN) {                                                             \
+        GP_MM2(MH, NH, FB, mt, ks)                                                                         \
+    } else if constexpr ((mt) < RBMAX) {      /* asymmetric tile: the row block only wave row 0 owns */    \
+        if (rb_hi) { GP_MM2(MH, NH, FB, mt, ks) }                                                          \
     }                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);   /* keep the pair between its wait and the next one */
 #define GP_MM4(MH, NH, FB, ks) GP_MM(MH, NH, FB, 0, ks) GP_MM(MH, NH, FB, 1, ks) GP_MM(MH, NH, FB, 2, ks) GP_MM(MH, NH, FB, 3, ks)
@@ -1007,7 +1029,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
             int tm, tn;
             walk.decode(it, tm, tn);
             const float* bl = has_bias ? reinterpret_cast<const float*>(bias_img) + wn * 64 + (lane >> 4) * 4 : nullptr;
-            epilogue_p<EPI, RB1>(p, acc, tm * BMv + wm * HW, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
+            const int m0w = tm * BMv + (wm ? HW0 : 0);
+            epilogue_p<EPI, RB1>(p, acc, m0w, (tn << 8) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage,
+                                 min(p.M, m0w + (wm ? TR::hw1 : TR::hw0)));
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1030,6 +1054,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
 #undef GP_RD_A
 #undef GP_RD_B
 #undef GP_MM
+#undef GP_MM2
 #undef GP_MM4
 #undef GP_WAIT
 }
@@ -1269,7 +1294,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn2_kernel(GemmArgs p, int ntiles
             walk.decode(it, tm, tn);
             const float* bl = has_bias ? reinterpret_cast<const float*>(smem + G3_RING + ((it & 1) << 10)) + wn * 64 + (lane >> 4) * 4
                                        : nullptr;
-            epilogue_p<EPI, 4>(p, acc, (tm << 8) + wm * 128, (tn << 7) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage);
+            epilogue_p<EPI, 4>(p, acc, (tm << 8) + wm * 128, (tn << 7) + wn * 64, tm * 4 + wm * 2, rs0, rs1, rsc, bl, stage, p.M);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1722,7 +1747,10 @@ int getmi_cu_count_impl() { return limited_cu(); }
 // the tile height, come out shorter than with 256 rows (RB1 = 4) even after charging the short tile 6 % (same
 // staging and barriers for 7/8 of the MFMAs; measured: N = 768 at M = 51 456 gains 3-6 %, N = 3072 would lose 3 %
 // although its rounds x height is 4 % smaller).  GETMI_GEMM_BM=256|224 forces one.
-static int pick_rb1(int M, int N) {
+static double tile_cost(int rb1);
+static int tile_rows_of(int rb1) { return rb1 == 5 ? 208 : 128 + 32 * rb1; }
+// allow208: the caller's epilogue has the asymmetric 208-row instantiation (plain bf16 and fp32 residual)
+static int pick_rb1(int M, int N, bool allow208 = false) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("GETMI_GEMM_BM");
@@ -1730,12 +1758,18 @@ static int pick_rb1(int M, int N) {
     }
     if (forced == 256) return 4;
     if (forced == 224) return 3;
+    if (forced == 208 && allow208) return 5;
     const int tiles_n = (N + 255) / 256, cus = num_cu();
-    auto span = [&](int bm) {
+    auto span = [&](int rb1) {      // rounds x relative time of one round of such tiles (tile_cost)
+        const int bm = tile_rows_of(rb1);
         const long tiles = (long)((M + bm - 1) / bm) * tiles_n;
-        return (double)((tiles + cus - 1) / cus) * bm;
+        return (double)((tiles + cus - 1) / cus) * tile_cost(rb1);
     };
-    return 1.06 * span(224) < span(256) ? 3 : 4;
+    int best = 4;
+    double c = span(4);
+    if (span(3) < c) { best = 3; c = span(3); }
+    if (allow208 && forced != 207 && span(5) < c - 1e-9) { best = 5; c = span(5); }      // GETMI_GEMM_BM=207: never 208
+    return best;
 }
 
 template <int EPI, int RB1>
@@ -1746,6 +1780,7 @@ static int launch_gemm_tn256(const GemmArgs& a, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
         attr_set = true;
     }
+    static_assert(RB1 != 5, "the asymmetric tile exists in the persistent kernel only");
     constexpr int BMv = 128 + 32 * RB1;
     const int grid = ((a.M + BMv - 1) / BMv) * ((a.N + 255) / 256);
     hipLaunchKernelGGL((gemm_tn256_kernel<EPI, RB1>), dim3(grid), dim3(512), G2_LDS, st, a);
@@ -1787,7 +1822,7 @@ static int launch_gemm_tn256p(const GemmArgs& a, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS + 1024 + 16384);
         attr_set = true;
     }
-    constexpr int BMv = 128 + 32 * RB1;
+    constexpr int BMv = TileRows<RB1>::bm;
     const int ntiles = ((a.M + BMv - 1) / BMv) * ((a.N + 255) / 256);
     const int grid = ntiles < num_cu() ? ntiles : num_cu();
     static int skew_env = -2;
@@ -1860,7 +1895,7 @@ static int launch_gemm_tn2(const GemmArgs& a, hipStream_t st) {
 // ---- tile-height plan ------------------------------------------------------------------------------------------
 // Relative time of one round of tiles of height 256 / 224 / 192 rows (RB1 = 4 / 3 / 2): a K-tile costs the same staging,
 // barriers and fragment reads at every height and 64 / 56 / 48 MFMAs per wave (measured for 224; linear model for 192).
-static double tile_cost(int rb1) { return rb1 == 4 ? 1.0 : rb1 == 3 ? 0.9275 : 0.87; }
+static double tile_cost(int rb1) { return rb1 == 4 ? 1.0 : rb1 == 3 ? 0.9275 : rb1 == 5 ? 0.895 : 0.87; }
 struct RowSeg { int rows, rb1; };
 // A problem whose tile count is not close to a multiple of the CU count loses a partial round.  For the epilogues that
 // only index by row (plain bf16, fp32 residual) the rows may be cut in two launches with different tile heights so that
@@ -1873,7 +1908,7 @@ static int plan_rows(int M, int N, bool may_split, RowSeg seg[2]) {
         mixed = e ? atoi(e) : 1;
     }
     const int tiles_n = (N + 255) / 256, cus = num_cu();
-    const int rb_u = pick_rb1(M, N), h_u = 128 + 32 * rb_u;
+    const int rb_u = pick_rb1(M, N, may_split), h_u = tile_rows_of(rb_u);
     const long tiles_u = (long)((M + h_u - 1) / h_u) * tiles_n;
     double best = (double)((tiles_u + cus - 1) / cus) * tile_cost(rb_u);
     seg[0] = RowSeg{M, rb_u};
@@ -1915,7 +1950,8 @@ static int launch_gemm_big(const GemmArgs& a, hipStream_t st) {
     if constexpr (can_persist) {
         if (a.K >= 128 && a.N % 8 == 0 && fits32 && g_tile_mode != 3) return launch_gemm_tn256p<EPI, RB1>(a, st);
     }
-    return launch_gemm_tn256<EPI, RB1>(a, st);
+    if constexpr (RB1 == 5) return launch_gemm_tn256<EPI, 3>(a, st);      // (not persistent-eligible: the 224-row one-tile kernel)
+    else return launch_gemm_tn256<EPI, RB1>(a, st);
 }
 
 template <int EPI>
@@ -1939,7 +1975,8 @@ static int launch_gemm_tn(const GemmArgs& a, hipStream_t st) {
             int rc;
             if constexpr (splittable) {
                 rc = seg[i].rb1 == 4 ? launch_gemm_big<EPI, 4>(s, st)
-                   : seg[i].rb1 == 3 ? launch_gemm_big<EPI, 3>(s, st) : launch_gemm_big<EPI, 2>(s, st);
+                   : seg[i].rb1 == 3 ? launch_gemm_big<EPI, 3>(s, st)
+                   : seg[i].rb1 == 5 ? launch_gemm_big<EPI, 5>(s, st) : launch_gemm_big<EPI, 2>(s, st);
             } else {
                 rc = seg[i].rb1 == 4 ? launch_gemm_big<EPI, 4>(s, st) : launch_gemm_big<EPI, 3>(s, st);
             }
