@@ -1758,7 +1758,6 @@ static int pick_rb1(int M, int N, bool allow208 = false) {
     }
     if (forced == 256) return 4;
     if (forced == 224) return 3;
-    if (forced == 208 && allow208) return 5;
     const int tiles_n = (N + 255) / 256, cus = num_cu();
     auto span = [&](int rb1) {      // rounds x relative time of one round of such tiles (tile_cost)
         const int bm = tile_rows_of(rb1);
@@ -1768,7 +1767,11 @@ static int pick_rb1(int M, int N, bool allow208 = false) {
     int best = 4;
     double c = span(4);
     if (span(3) < c) { best = 3; c = span(3); }
-    if (allow208 && forced != 207 && span(5) < c - 1e-9) { best = 5; c = span(5); }      // GETMI_GEMM_BM=207: never 208
+    // The 208-row tile is OFF by default: measured in the C2 step (three interleaved rounds, profiles/r03_ab_208.txt) 34.05-
+    // 34.29 ms with it vs 33.99-34.06 without; per shape it moves proj dgrad 72 -> 69 us and fc1 dgrad 217 -> 210 us but proj /
+    // fc2 forward +-1 us: the third round's idle CUs were not what these GEMMs wait for.  GETMI_GEMM_BM=208 selects it where
+    // the round model prefers it (kept under test).
+    if (allow208 && forced == 208 && span(5) < c - 1e-9) { best = 5; c = span(5); }
     return best;
 }
 
