@@ -104,15 +104,18 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& pdf) {
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
-    // ((x*x)*k so that hipcc packs both multiplies of an element pair; the 0.5 of Phi is folded into the coefficients)
-    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);   // exp(-x^2/2)
-    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    poly = fmaf(poly, t, 0.5f * 1.421413741f);
-    poly = fmaf(poly, t, 0.5f * -0.284496736f);
-    poly = fmaf(poly, t, 0.5f * 0.254829592f);
-    const float tail = poly * t * e;                 // 0.5*erfc(|x|/sqrt2)
-    Phi = x >= 0.f ? 1.0f - tail : tail;
-    pdf = 0.3989422804014327f * e;
+    // pdf(x) = exp(-x^2/2)/sqrt(2 pi) straight out of the exponential (log2 of the constant rides in the fma); the
+    // polynomial's coefficients carry 0.5 (of Phi) * sqrt(2 pi) (to undo that constant): tail = poly * t * pdf
+    pdf = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170f, -1.3257480647361593f));
+    constexpr float C = 0.5f * 2.5066282746310002f;
+    float poly = fmaf(C * 1.061405429f, t, C * -1.453152027f);
+    poly = fmaf(poly, t, C * 1.421413741f);
+    poly = fmaf(poly, t, C * -0.284496736f);
+    poly = fmaf(poly, t, C * 0.254829592f);
+    // 0.5*erfc(|x|/sqrt2) = poly*t*pdf =: tail in (0, 0.5];  Phi = x >= 0 ? 1 - tail : tail = 0.5 + copysign(0.5 - tail, x):
+    // one v_bfi instead of compare + select + subtract per element (the fc1 epilogue is VALU-issue bound: round 3)
+    const float h = fmaf(-(poly * t), pdf, 0.5f);
+    Phi = 0.5f + __builtin_copysignf(h, x);
 }
 __device__ __forceinline__ float gelu_f(float x) {
     float Phi, pdf;
