@@ -52,12 +52,15 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
 // d block) leave a kernel as 8-byte pieces on 64 different rows per store instruction, which is store-ISSUE bound
 // (measured with s_memtime stamps: 4-7 k cycles for the dK / dV rows of one backward workgroup).  Staged through a
 // wave-private LDS block [rows][128 B] (16-B chunk index XOR (row & 7)) they leave as whole 128-byte rows instead:
-// 16 bytes per lane, 8 rows per instruction.
+// 16 bytes per lane, 8 rows per instruction.  An 8-byte LDS write is serviced in groups of 16 consecutive lanes (16
+// consecutive rows here) over 32 banks = 128 B, so the (chunk, half) slot must differ across 16 rows: rows with bit 3 set
+// hold the two 8-byte halves of every chunk swapped, and the read-back swaps them again (2-way conflicts before).
 __device__ __forceinline__ void stage_row_piece(char* blk, int row, int d0, uint2 v) {
-    *reinterpret_cast<uint2*>(blk + row * 128 + ((((d0 >> 3) ^ (row & 7)) << 4) | ((d0 & 4) << 1))) = v;
+    *reinterpret_cast<uint2*>(blk + row * 128 + ((((d0 >> 3) ^ (row & 7)) << 4) | ((((d0 >> 2) ^ (row >> 3)) & 1) << 3))) = v;
 }
 __device__ __forceinline__ uint4 stage_row_chunk(const char* blk, int row, int chunk) {
-    return *reinterpret_cast<const uint4*>(blk + row * 128 + ((chunk ^ (row & 7)) << 4));
+    const uint4 v = *reinterpret_cast<const uint4*>(blk + row * 128 + ((chunk ^ (row & 7)) << 4));
+    return ((row >> 3) & 1) ? make_uint4(v.z, v.w, v.x, v.y) : v;
 }
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
@@ -746,9 +749,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ void bs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // (hipcc guards plain LDS WRITES the same way, so the few stores inside the streamed section are asm as well)
-__device__ __forceinline__ void bs_write2_b64(unsigned addr, u32x2_t a, u32x2_t b) {      // addr, addr + 16
-    asm volatile("ds_write2_b64 %0, %1, %2 offset1:2" ::"v"(addr), "v"(a), "v"(b) : "memory");
-}
 __device__ __forceinline__ void bs_write_b64(unsigned addr, u32x2_t v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -839,12 +839,15 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     auto dq_tile = [&](const bf16x8 (&ktf)[8], int sl, int dsbuf, int ln) {
         const int gi = ln >> 4, qq = (ln >> 2) & 3, pp = ln & 3;
         const int qh = wave & 1, dblk = wave >> 1, klo = 8 * gi + qq;
-        const unsigned dsa = smem0 + BW_DS + dsbuf * 16384 +
-                             (unsigned)(klo * 64 + ((((qh ^ ((klo >> 3) & 1)) << 5)) | ((4 * pp) << 1)));
+        // this lane's piece = 8-byte slot (qh*4 + pp) of key row klo (and klo + 4), slots XORed with (key >> 1) & 7 (see the
+        // writer); (klo + 4) >> 1 differs from klo >> 1 by bit 1 only (klo & 7 <= 3)
+        const unsigned dsx = (unsigned)(((qh * 4 + pp) ^ ((klo >> 1) & 7)) << 3);
+        const unsigned dsa = smem0 + BW_DS + dsbuf * 16384 + (unsigned)(klo * 64) + dsx;
+        const unsigned dsb = smem0 + BW_DS + dsbuf * 16384 + (unsigned)(klo * 64) + (dsx ^ 16u);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         tr64_t ta[8], tb[8];
-        tr_issue8ab<0, 256, 2048, 2048 + 256, 4096, 4096 + 256, 6144, 6144 + 256>(dsa, dsa, ta);
-        tr_issue8ab<8192, 8192 + 256, 10240, 10240 + 256, 12288, 12288 + 256, 14336, 14336 + 256>(dsa, dsa, tb);
+        tr_issue8ab<0, 256, 2048, 2048 + 256, 4096, 4096 + 256, 6144, 6144 + 256>(dsa, dsb, ta);
+        tr_issue8ab<8192, 8192 + 256, 10240, 10240 + 256, 12288, 12288 + 256, 14336, 14336 + 256>(dsa, dsb, tb);
         tr_wait16(ta, tb);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -1039,8 +1042,14 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         for (int kk = 0; kk < 4; ++kk) fk[kk] += 32768 - wave * 4096;      // now the Q piece of slice 0
         const unsigned st_a = smem0 + BS_STAT + r * 16;
         const unsigned hmask = h2 ? 0u : 0xffffffffu;      // the constants ride on k = 0..2 of the extra K step: lanes of half 0
-        const unsigned ds_wa = smem0 + BW_DS + (wave * 32 + r) * 64 + ((((wave * 32 + r) >> 3) & 1) << 5) + 8 * h2;
-        const unsigned ds_wb = smem0 + BW_DS + (wave * 32 + r) * 64 + (((((wave * 32 + r) >> 3) & 1) ^ 1) << 5) + 8 * h2;
+        // dS^T image of the streamed kernel: row = key (64 B = eight 8-byte slots of 4 queries), slot index XOR (key >> 1) & 7.
+        // A ds_write_b64 is serviced in groups of 16 consecutive lanes (= 16 consecutive keys here) over 32 banks = two
+        // 64-byte rows: the 8 keys of one parity must hit 8 different slots.  (Halves swapped by (key >> 3) & 1, the staged
+        // kernel's layout, was a 4-way conflict on every write: 29 % of this kernel's LDS cycles.)
+        const unsigned ds_s0 = (unsigned)(h2 ^ (((wave * 32 + r) >> 1) & 7));
+        const unsigned ds_wa = smem0 + BW_DS + (wave * 32 + r) * 64 + (ds_s0 << 3);            // queries 4h2..      (slot h2)
+        const unsigned ds_wb = smem0 + BW_DS + (wave * 32 + r) * 64 + ((ds_s0 ^ 4u) << 3);     // queries 16 + 4h2.. (slot 4 + h2)
+        const int ds_d2 = (ds_s0 & 2u) ? -16 : 16;                                             // to slot ^ 2: queries + 8
         STAMP(4);
         int dsbuf = 0;
         for (int sl = 0; sl < nsl; ++sl) {
@@ -1113,12 +1122,13 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                 dsf[0] = pack8(dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[7]);
                 dsf[1] = pack8(dp[8], dp[9], dp[10], dp[11], dp[12], dp[13], dp[14], dp[15]);
                 {
-                    // dS^T image: row = key, 32 q per row (64 B); 32-B halves swapped when (key>>3)&1; this lane's 4 pieces
-                    // of 4 queries sit at A, A + 16 (queries 4h2.., 8 + 4h2..) and B, B + 16 (16 + 4h2.., 24 + 4h2..)
+                    // dS^T image (layout at ds_wa): this lane's 4 pieces of 4 queries (4h2.., 8 + 4h2.., 16 + 4h2.., 24 + 4h2..)
                     const u32x2_t* d2 = reinterpret_cast<const u32x2_t*>(dsf);
                     const unsigned o = dsbuf * 16384;
-                    bs_write2_b64(ds_wa + o, d2[0], d2[1]);
-                    bs_write2_b64(ds_wb + o, d2[2], d2[3]);
+                    bs_write_b64(ds_wa + o, d2[0]);
+                    bs_write_b64(ds_wa + o + ds_d2, d2[1]);
+                    bs_write_b64(ds_wb + o, d2[2]);
+                    bs_write_b64(ds_wb + o + ds_d2, d2[3]);
                 }
                 tr_wait16(ta, tb);
                 // dV^T[d][key] += dO^T[d][q].P[q][key] ; dK^T[d][key] += Q^T[d][q].dS[q][key]

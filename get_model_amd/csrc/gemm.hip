@@ -739,12 +739,13 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             for (int outp = 0; outp < (EpiKind<EPI>::gelu ? 2 : 1); ++outp) {
                 u32x4 dd[2];
                 // 8-byte piece of (b, c): columns b*16 + c*4 .. +3 -> 16-B chunk (b*2 + (c>>1)), half (c&1)
-                if (outp == 0)
-                    stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qv[0], qv[1],
-                                       qv[2], qv[3], dd[0], dd[1]);
-                else
-                    stage_w64x4_r128x2(sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + ((c & 1) << 3), ra, qg[0], qg[1],
-                                       qg[2], qg[3], dd[0], dd[1]);
+                // (the 8-byte half is XORed with row >> 3: a ds_write_b64 is serviced in groups of 16 consecutive lanes = the 16
+                //  rows of one c over 32 banks, so (chunk, half) must take 16 different values per group; rows 8..15 then hold
+                //  their two halves swapped, which the read-back undoes by renaming registers)
+                const unsigned wa64 = sbase + r * 128 + ((((c >> 1) ^ (r & 7))) << 4) + (((c & 1) ^ (r >> 3)) << 3);
+                if (outp == 0) stage_w64x4_r128x2(wa64, ra, qv[0], qv[1], qv[2], qv[3], dd[0], dd[1]);
+                else stage_w64x4_r128x2(wa64, ra, qg[0], qg[1], qg[2], qg[3], dd[0], dd[1]);
+                dd[1] = (u32x4){dd[1][2], dd[1][3], dd[1][0], dd[1][1]};
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
                     const int row = ps * 8 + rrow;
