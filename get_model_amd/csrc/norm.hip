@@ -9,6 +9,7 @@
 //     partial[blk] = column sums over the block's rows of {dy*xhat, dy, dz}
 // Algorithmic bytes per row (D=768): fwd 4*D read + 2*D write; bwd (2+4+4)*D read + (4+2)*D write.
 #include "common.h"
+#include <stdlib.h>
 static constexpr bool kNtLn = GETMI_NT_LN != 0;    // activations are streamed: read once, written once
 
 template <int NV>  // D = NV * 256
@@ -192,9 +193,27 @@ int getmi_colreduce_impl(const float* partial, float* out0, float* out1, float* 
     return GETMI_OK;
 }
 
-static int ln_grid(int M) {
+static int ln_grid_cap(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return v < 1 ? dflt : v;
+}
+static int ln_grid(int M) {      // forward
+    static int cap = 0;
+    if (cap == 0) cap = ln_grid_cap("GETMI_LN_GRID", 1024);
     int g = (M + 3) / 4;
-    if (g > 1024) g = 1024;
+    if (g > cap) g = cap;
+    return g < 1 ? 1 : g;
+}
+// Backward: TWO workgroups per CU.  Measured in the training step at M = 51 456 (tools/exp_ln_grid.sh, MI355X, us per launch):
+// 256 workgroups 75.8, 512 76.8, 768 79.8, 1024 86.9, 384 83.1, 640 82.0 -- whole multiples of the CU count win and fewer
+// resident rows win (the band of rows in flight stays narrow: four streams per row); 512 keeps two workgroups per CU
+// for the case where the CU limit of an overlapped gradient exchange takes some CUs away.
+static int ln_bwd_grid(int M) {
+    static int cap = 0;
+    if (cap == 0) cap = ln_grid_cap("GETMI_LN_BWD_GRID", 512);      // 2 x 256 CUs (MI355X)
+    int g = (M + 3) / 4;
+    if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
 
@@ -213,7 +232,7 @@ int getmi_ln_fwd_impl(const float* x, const float* gamma, const float* beta, bf1
     return GETMI_OK;
 }
 
-size_t getmi_ln_bwd_workspace_bytes(int M, int D) { return (size_t)3 * ln_grid(M) * D * sizeof(float); }
+size_t getmi_ln_bwd_workspace_bytes(int M, int D) { return (size_t)3 * ln_bwd_grid(M) * D * sizeof(float); }
 
 // dgamma/dbeta/dbias_prev: [D] each (dbias_prev may be null); accumulate: add into existing values.
 // dres_bf16 / dx_bf16: element type of the residual-gradient stream on the way in / out (0 = fp32, 1 = bf16).
@@ -228,7 +247,7 @@ int getmi_ln_bwd_impl(const bf16_t* dy, const float* x, const float* mean, const
     GETMI_CHECK_ARG(!rowscale || rows_per_sample > 0, "ln_bwd: rows_per_sample");
     // (dbias_prev without dz: the column sums of rowscale * dx are formed without storing that tensor -- the DropPath fold of
     //  functional.py, whose GEMMs consume the unscaled bf16 dx)
-    const int g = ln_grid(M);
+    const int g = ln_bwd_grid(M);
     const int zsum = (dbias_prev != nullptr && dz == nullptr) ? 1 : 0;
     float* partial = reinterpret_cast<float*>(workspace);
 #define LN_BWD_LAUNCH2(NV, RB, XB)                                                                                \

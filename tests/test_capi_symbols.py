@@ -32,7 +32,7 @@ def test_version_and_error_channel_without_gpu():
     assert h.getmi_version() == 100
     assert h.getmi_arch() == b"gfx950"
     assert lib.query("getmi_gemm_wgrad_workspace_bytes", 51456, 768, 768) >= 768 * 768 * 4
-    assert lib.query("getmi_layernorm_bwd_workspace_bytes", 51456, 768) == 3 * 1024 * 768 * 4
+    assert lib.query("getmi_layernorm_bwd_workspace_bytes", 51456, 768) == 3 * 512 * 768 * 4      # 2 workgroups per CU
 
 
 def test_product_path_has_no_cpu_fallback():
