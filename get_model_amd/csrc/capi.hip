@@ -9,6 +9,7 @@ struct GemmArgs {
 };
 int getmi_gemm_tn_colsum_rows(int M, int N);
 int getmi_gemm_tn_colsum_rows_max(int M, int N);
+int getmi_gemm_tn_colsum_dense();
 int getmi_cu_scope_enter(int all_cus);
 void getmi_cu_scope_leave(int token);
 struct CuScope {     // one CU-budget snapshot per C-ABI call (see gemm.hip)
@@ -93,14 +94,18 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
         GETMI_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace % 16 == 0),
                         "gemm_tn: dbias needs a workspace of getmi_gemm_tn_workspace_bytes(M, N)");
         a.colsum = reinterpret_cast<float*>(workspace);
-        // kernels write one partial row per (tile, wave-row[, half]); rows a variant does not use must read as zero
-        if (hipMemsetAsync(workspace, 0, need, ST(stream)) != hipSuccess) {
+        // kernels write two partial rows per (tile, wave-row): every entry of the rows this launch uses is written (the
+        // staged epilogue zero-fills the row it has no sums for), so the table is cleared only for the diagnostic generation
+        if (!getmi_gemm_tn_colsum_dense() && hipMemsetAsync(workspace, 0, need, ST(stream)) != hipSuccess) {
             getmi_set_error("gemm_tn: workspace memset failed");
             return GETMI_ERR_LAUNCH;
         }
     }
     if (int rc = getmi_gemm_tn_impl(epi, a, ST(stream))) return rc;
-    if (dbias) return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, getmi_gemm_tn_colsum_rows_max(M, N), N, 0, ST(stream));
+    if (dbias) {
+        const int rows = getmi_gemm_tn_colsum_dense() ? getmi_gemm_tn_colsum_rows(M, N) : getmi_gemm_tn_colsum_rows_max(M, N);
+        return getmi_colreduce_impl(a.colsum, dbias, nullptr, nullptr, rows, N, 0, ST(stream));
+    }
     return 0;
 }
 size_t getmi_gemm_wgrad_workspace_bytes(int M, int N1, int N2) {

@@ -769,6 +769,9 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             const unsigned off = (r == 0 && n < p.N) ? (unsigned)(((size_t)prow * p.N + n) * 4) : OOB_OFF;
             const f32x4 cv = {cc.x, cc.y, cc.z, cc.w};
             st_b128(__builtin_bit_cast(u32x4, cv), off, rsc);
+            // the partial-row table has two rows per wave row (the one-tile kernel's epilogue sums its two 64-row halves
+            // separately); this epilogue fills the second with zeros so that no memset of the table is needed
+            st_b128((u32x4){0u, 0u, 0u, 0u}, off == OOB_OFF ? OOB_OFF : off + (unsigned)p.N * 4u, rsc);
         }
     }
 }
@@ -2010,6 +2013,9 @@ int getmi_gemm_tn_colsum_rows(int M, int N) {
     const int bm = pick_rb1(M, N) == 3 ? 224 : 256;
     return ((M + bm - 1) / bm) * 4;
 }
+// 1 when the launch this call would make writes EVERY entry of its getmi_gemm_tn_colsum_rows(M, N) partial rows (no clear
+// needed); the diagnostic two-workgroup generation (GETMI_GEMM_GEN=2) uses its own tile grid and leaves rows untouched
+int getmi_gemm_tn_colsum_dense() { return gemm_gen_mode() == 2 ? 0 : 1; }
 // ... and its upper bound over every tile choice (what a workspace must hold whatever the CU limit is at launch time)
 int getmi_gemm_tn_colsum_rows_max(int M, int N) {
     GemmArgs a{};
