@@ -5,11 +5,12 @@
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; int M, N, K, lda, ldb; void* out0; void* out1; int ldo; const float* bias;
     const float* resid; const float* rowscale; int rows_per_sample; const bf16_t* aux; int ldaux;
-    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0; int prescaled;
+    const uint8_t* mask; const float* mask_token; int regions_per_sample; float* colsum; int row0; int prescaled; int blocked;
 };
 int getmi_gemm_tn_colsum_rows(int M, int N);
 int getmi_gemm_tn_colsum_rows_max(int M, int N);
 int getmi_gemm_tn_colsum_dense();
+int getmi_gemm_tn_blocked_ok_impl(int M, int N, int K);
 int getmi_cu_scope_enter(int all_cus);
 void getmi_cu_scope_leave(int token);
 struct CuScope {     // one CU-budget snapshot per C-ABI call (see gemm.hip)
@@ -79,6 +80,7 @@ int getmi_cast_transpose_f32_bf16(const float* src, void* dst, int R, int C, voi
 int getmi_qkv_bias(const float* q_bias, const float* v_bias, float* out, int D, void* stream) {
     return getmi_qkv_bias_impl(q_bias, v_bias, out, D, ST(stream));
 }
+int getmi_gemm_tn_blocked_ok(int M, int N, int K) { return getmi_gemm_tn_blocked_ok_impl(M, N, K); }
 size_t getmi_gemm_tn_workspace_bytes(int M, int N) { return (size_t)getmi_gemm_tn_colsum_rows_max(M, N) * N * sizeof(float); }
 int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* out0, void* out1,
                   int ldo, const float* bias, const float* resid, const float* rowscale, int rows_per_sample,
@@ -86,7 +88,7 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
                   float* dbias, void* workspace, size_t workspace_bytes, int flags, void* stream) {
     CuScope scope(false);      // tile choice, partial-row count and launch all see one CU budget
     GemmArgs a{BF(A), BF(B), M, N, K, lda, ldb, out0, out1, ldo, bias, resid, rowscale, rows_per_sample, BF(aux), ldaux,
-               mask, mask_token, regions_per_sample, nullptr, 0, (flags & 1) ? 1 : 0};
+               mask, mask_token, regions_per_sample, nullptr, 0, (flags & 1) ? 1 : 0, (flags & 2) ? 1 : 0};
     if (dbias) {
         GETMI_CHECK_ARG(epi == 3 || epi == 7, "gemm_tn: dbias (fused column sums) is only produced by the DGELU / DMUL epilogues");
         // partial rows for ANY tile height the launcher may pick (rows a variant does not write stay zero and add nothing)

@@ -74,6 +74,12 @@ template <bool NT> __device__ __forceinline__ float4 load_f4(const float* p) {
         return make_float4(v[0], v[1], v[2], v[3]);
     } else return *reinterpret_cast<const float4*>(p);
 }
+template <bool NT> __device__ __forceinline__ uint4 load_u4(const void* p) {
+    if constexpr (NT) {
+        const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    } else return *reinterpret_cast<const uint4*>(p);
+}
 template <bool NT> __device__ __forceinline__ uint2 load_u2(const void* p) {
     if constexpr (NT) {
         const nt_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x2*>(p));

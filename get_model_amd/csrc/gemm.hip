@@ -64,6 +64,9 @@ struct GemmArgs {
     int row0;        // first row of this launch within the caller's problem (split launches; only the row scale uses it)
     int prescaled;   // EPI_BIAS_RESID: A already carries the row scale (DropPath fold, functional.py): out = resid + acc +
                      // rowscale * bias instead of resid + rowscale * (acc + bias)
+    int blocked;     // EPI_BIAS_GELUG: out0 / EPI_DMUL: aux is in the BLOCKED layout (getmi355.h, flags bit 1): a private
+                     // hand-over format between the two, [row block of 16][column block of 64][2][64 lanes][16 B] -- the
+                     // accumulator layout of a wave's 16 x 64 block, so it leaves and returns as whole 1-KiB pieces
 };
 
 #define BM 128
@@ -696,12 +699,26 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
     for (int half = 0; half < 2; ++half) {
         uint2 uv[4][4];
         if (EpiKind<EPI>::dgelu) {
+            if (EPI == EPI_DMUL && p.blocked) {
+                // blocked aux: this lane's four 8-byte pieces of row block (half*4 + a) are two 16-byte loads, 1 KiB per wave
+                // and instruction (row blocks past the end re-read the last one: their results are never stored)
+                const int nrb = (p.M + 15) >> 4, ncb = p.N >> 6;
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a) {
+                    const int rb = min((m0w >> 4) + half * 4 + a, nrb - 1);
+                    const bf16_t* blk = p.aux + ((size_t)rb * ncb + (n0w >> 6)) * 1024 + lane * 8;
+                    const uint4 lo = load_u4<GETMI_NT_EPI_LOADS != 0>(blk), hi = load_u4<GETMI_NT_EPI_LOADS != 0>(blk + 512);
+                    uv[a][0] = make_uint2(lo.x, lo.y); uv[a][1] = make_uint2(lo.z, lo.w);
+                    uv[a][2] = make_uint2(hi.x, hi.y); uv[a][3] = make_uint2(hi.z, hi.w);
+                }
+            } else {
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    uv[a][b] = load_u2<GETMI_NT_EPI_LOADS != 0>(p.aux + (size_t)min(em + (half * 4 + a) * 16, p.M - 1) * p.ldaux +
-                                                                min(en + b * 16, p.N - 4));
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        uv[a][b] = load_u2<GETMI_NT_EPI_LOADS != 0>(p.aux + (size_t)min(em + (half * 4 + a) * 16, p.M - 1) * p.ldaux +
+                                                                    min(en + b * 16, p.N - 4));
+            }
         }
 #pragma unroll
         for (int a = 0; a < (half ? RBX : 4); ++a) {
@@ -737,6 +754,17 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
             }
 #pragma unroll
             for (int outp = 0; outp < (EpiKind<EPI>::gelu ? 2 : 1); ++outp) {
+                if (EPI == EPI_BIAS_GELUG && outp == 0 && p.blocked) {
+                    // blocked out0 (the stored derivative, read back only by the DMUL epilogue of the same shape): the
+                    // accumulator layout leaves as it is, two whole 1-KiB pieces per wave and row block, no LDS pass.
+                    // Same number of store instructions as the staged form (the counted waits rely on it).
+                    const unsigned boff = (m0w + ab * 16 < row_end)
+                        ? (unsigned)((((size_t)((m0w >> 4) + ab) * (p.N >> 6) + (n0w >> 6)) * 2048) + lane * 16) : OOB_OFF;
+                    st_b128<EpiNt<EPI>::value>((u32x4){qv[0][0], qv[0][1], qv[1][0], qv[1][1]}, boff, rs0);
+                    st_b128<EpiNt<EPI>::value>((u32x4){qv[2][0], qv[2][1], qv[3][0], qv[3][1]},
+                                               boff == OOB_OFF ? OOB_OFF : boff + 1024u, rs0);
+                    continue;
+                }
                 u32x4 dd[2];
                 // 8-byte piece of (b, c): columns b*16 + c*4 .. +3 -> 16-B chunk (b*2 + (c>>1)), half (c&1)
                 // (the 8-byte half is XORed with row >> 3: a ds_write_b64 is serviced in groups of 16 consecutive lanes = the 16
@@ -834,7 +862,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256p_kernel(GemmArgs p, int nti
     const unsigned esz = (EPI == EPI_BIAS_RESID) ? 4u : 2u;
     // (a NULL out0 -- allowed for the two-output GELU epilogues -- becomes an empty buffer: its stores are dropped by the
     //  bounds check, the instruction count the waits rely on stays the same)
-    const u32x4 rs0 = make_rsrc(p.out0 ? p.out0 : p.out1, p.out0 ? (unsigned)((size_t)p.M * p.ldo * esz) : 0u);
+    // (a blocked out0 -- GemmArgs::blocked -- is padded to whole 16-row blocks)
+    const int rows0 = (EPI == EPI_BIAS_GELUG && p.blocked) ? ((p.M + 15) & ~15) : p.M;
+    const u32x4 rs0 = make_rsrc(p.out0 ? p.out0 : p.out1, p.out0 ? (unsigned)((size_t)rows0 * p.ldo * esz) : 0u);
     const u32x4 rs1 = make_rsrc(p.out1 ? p.out1 : p.out0, (unsigned)((size_t)p.M * p.ldo * esz));
     const u32x4 rsc = make_rsrc(p.colsum ? (const void*)p.colsum : (const void*)p.out0,
                                 p.colsum ? (unsigned)((size_t)((p.M + BMv - 1) / BMv) * 4 * p.N * 4) : 0u);
@@ -2024,8 +2054,26 @@ int getmi_gemm_tn_colsum_rows_max(int M, int N) {
     return ((M + 223) / 224) * 4;
 }
 
+// Can a GEMM of this shape hand gelu'(u) from the BIAS_GELUG epilogue to the DMUL epilogue in the blocked layout
+// (GemmArgs::blocked)?  Only the persistent 256-row-tile kernel implements it; the answer depends on the shape and on
+// process-wide diagnostic switches, never on the CU limit, so the forward and the backward call of one layer agree.
+int getmi_gemm_tn_blocked_ok_impl(int M, int N, int K) {
+    GemmArgs a{};
+    a.M = M; a.N = N; a.K = K;
+    if (M <= 0 || N <= 0 || K <= 0 || !use_big_tile(a) || g_tile_mode == 3 || gemm_gen_mode() != 0) return 0;
+    const size_t lim = 0xF0000000ull;
+    return (K >= 128 && K % BK == 0 && N % 64 == 0 && (size_t)M * K * 2 < lim && (size_t)N * K * 2 < lim &&
+            (size_t)((M + 15) & ~15) * N * 2 < lim) ? 1 : 0;
+}
+
 int getmi_gemm_tn_impl(int epi, const GemmArgs& a, hipStream_t st) {
     GETMI_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    if (a.blocked) {
+        GETMI_CHECK_ARG(epi == EPI_BIAS_GELUG || epi == EPI_DMUL, "gemm_tn: the blocked layout (flags bit 1) exists for epilogues 6 (out0) and 7 (aux) only");
+        GETMI_CHECK_ARG(getmi_gemm_tn_blocked_ok_impl(a.M, a.N, a.K) && a.lda == a.K && a.ldb == a.K &&
+                        (epi == EPI_BIAS_GELUG ? a.ldo == a.N : (a.ldaux == a.N && a.ldo == a.N)),
+                        "gemm_tn: blocked layout not available for M=%d N=%d K=%d (ask getmi_gemm_tn_blocked_ok; dense operands)", a.M, a.N, a.K);
+    }
     GETMI_CHECK_ARG(a.K % BK == 0, "gemm_tn: K=%d must be a multiple of %d (pad the operands)", a.K, BK);
     GETMI_CHECK_ARG(a.N % 4 == 0 && a.ldo % 4 == 0, "gemm_tn: N=%d and ldo=%d must be multiples of 4", a.N, a.ldo);
     GETMI_CHECK_ARG(a.lda % 8 == 0 && a.ldb % 8 == 0, "gemm_tn: lda/ldb must be multiples of 8 (16-byte rows)");

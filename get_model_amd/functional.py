@@ -233,6 +233,7 @@ class _GradStream:
 # oracle identical to 5 digits: the rounding of dx to bf16 is below what the bf16 GEMM operands already carry).
 # GETMI_BF16_GRAD=0 restores the fp32 stream.
 _BF16_GRAD = os.environ.get("GETMI_BF16_GRAD", "1") != "0"
+_BLOCKED_AUX = os.environ.get("GETMI_BLOCKED_AUX", "1") != "0"      # gelu'(u) in the kernels' blocked layout (EncoderBlock)
 STREAM = _GradStream()
 
 
@@ -399,11 +400,13 @@ class EncoderBlock(torch.autograd.Function):
         # --- MLP branch ---
         h2, mean2, rstd2 = K.layernorm_fwd(x_mid, n2w.detach(), n2b.detach(), eps)
         Fh = fc1_w.shape[0]
-        u = torch.empty(M, Fh, dtype=BF16, device=dev) if needs_bwd else None     # inference: gelu'(.) is not stored
-        g = torch.empty(M, Fh, dtype=BF16, device=dev)
-        # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply
+        # u holds gelu'(fc1 output), not the pre-activation: the backward epilogue is then a plain multiply.  Nobody but
+        # that epilogue reads it, so where the kernels allow it travels in their own blocked layout (getmi355.h)
+        blocked = needs_bwd and _BLOCKED_AUX and K.gemm_tn_blocked_ok(M, Fh, D)
+        u = torch.empty(K.blocked_rows(M) if blocked else M, Fh, dtype=BF16, device=dev) if needs_bwd else None
+        g = torch.empty(M, Fh, dtype=BF16, device=dev)                            # (inference: gelu'(.) is not stored)
         K.gemm_tn(K.EPI_BIAS_GELUG, h2, w_bf16(fc1_w), u, out1=g, bias=fc1_b.detach(),
-                  rowscale=scale2 if fold else None, rows_per_sample=T)
+                  rowscale=scale2 if fold else None, rows_per_sample=T, M=M, blocked=blocked)
         x_out = torch.empty(M, D, dtype=torch.float32, device=dev)
         K.gemm_tn(K.EPI_BIAS_RESID, g, w_bf16(fc2_w), x_out, bias=fc2_b.detach(), resid=x_mid, rowscale=scale2,
                   rows_per_sample=T, prescaled=fold and scale2 is not None)
@@ -413,6 +416,7 @@ class EncoderBlock(torch.autograd.Function):
         ctx.dims = (B, T, D, H, att_scale)
         ctx.up = (bool(up_block), up_scale)
         ctx.fold = fold
+        ctx.blocked = blocked
         out = x_out.view(B, T, D)
         ctx.gids = (None, None)
         ctx.x_ref = None
@@ -458,9 +462,9 @@ class EncoderBlock(torch.autograd.Function):
             dfc2_b = db0 if scale2 is None else K.scale_cast(full, scale2, T)[1]
         # ---- MLP branch (g = s2 * gelu(u) and u = s2 * gelu'(u) carry the DropPath factor) ----
         dfc2_w = K.gemm_wgrad(dxb, g, out=grad_buffer(fc2_w)) if need[12] else None
-        du = torch.empty_like(u)
+        du = torch.empty(M, u.shape[1], dtype=BF16, device=dev)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
-        K.gemm_tn(K.EPI_DMUL, dxb, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)     # (dx @ W2) * s2 * gelu'(.), + column sums
+        K.gemm_tn(K.EPI_DMUL, dxb, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b, blocked=ctx.blocked)   # (dx @ W2) * s2 * gelu'(.), + column sums
         dfc1_w = K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w)) if need[10] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1
@@ -519,9 +523,9 @@ class EncoderBlock(torch.autograd.Function):
         hit = HANDOFF.take(dx_out, scale2)
         dz2, dfc2_b = hit if hit is not None else K.scale_cast(dx_out, scale2, T)
         dfc2_w = side.run(lambda: K.gemm_wgrad(dz2, g, out=grad_buffer(fc2_w))) if need[12] else None
-        du = torch.empty_like(u)
+        du = torch.empty(M, u.shape[1], dtype=BF16, device=dev)
         dfc1_b = torch.empty(u.shape[1], dtype=torch.float32, device=dev) if need[11] else None
-        K.gemm_tn(K.EPI_DMUL, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b)   # (dz2 @ W2) * gelu'(.), + column sums
+        K.gemm_tn(K.EPI_DMUL, dz2, w_bf16_t(fc2_w), du, aux=u, dbias=dfc1_b, blocked=ctx.blocked)   # (dz2 @ W2) * gelu'(.), + column sums
         dfc1_w = side.run(lambda: K.gemm_wgrad(du, h2, out=grad_buffer(fc1_w))) if need[10] else None
         dh2 = torch.empty(M, D, dtype=BF16, device=dev)
         K.gemm_tn(K.EPI_BF16, du, w_bf16_t(fc1_w), dh2)                        # du @ W1

@@ -83,9 +83,10 @@ def qkv_bias(q_bias, v_bias):
 
 
 def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, rows_per_sample=0, aux=None,
-            mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None, prescaled=False):
+            mask=None, mask_token=None, regions_per_sample=0, M=None, dbias=None, prescaled=False, blocked=False):
     """out = epilogue(A[M,K] @ B[N,K]^T).  A, B bf16 row-major; out0/out1 preallocated (out0 may be None for the
-    two-output GELU epilogues: only gelu(u) is stored)."""
+    two-output GELU epilogues: only gelu(u) is stored).  blocked: out0 of EPI_BIAS_GELUG / aux of EPI_DMUL is a
+    `blocked_rows(M)` x N buffer in the hand-over layout of getmi355.h (flags bit 1; ask gemm_tn_blocked_ok first)."""
     _chk(A, B, out0, out1, bias, resid, rowscale, aux, mask, mask_token)
     M = A.shape[0] if M is None else M
     K = A.shape[1]
@@ -96,9 +97,18 @@ def gemm_tn(epi, A, B, out0, out1=None, bias=None, resid=None, rowscale=None, ro
     ldo = (out0 if out0 is not None else out1).shape[-1]
     lib.call("getmi_gemm_tn", epi, A, B, M, N, K, A.stride(0), B.stride(0), out0, out1, ldo, bias,
              resid, rowscale, rows_per_sample, aux, 0 if aux is None else aux.shape[-1], mask, mask_token,
-             regions_per_sample, dbias, ws, 0 if ws is None else ws.numel(), 1 if prescaled else 0)
+             regions_per_sample, dbias, ws, 0 if ws is None else ws.numel(), (1 if prescaled else 0) | (2 if blocked else 0))
     _prof_end(e0, "gemm_tn_kernel<" + _EPI_NAMES[epi] + ">", 2.0 * M * N * K)
     return out0
+
+
+def gemm_tn_blocked_ok(M, N, K):
+    """May fc1's forward hand gelu'(u) to fc2's data gradient in the blocked layout (same answer for both calls)?"""
+    return bool(lib.query("getmi_gemm_tn_blocked_ok", M, N, K))
+
+
+def blocked_rows(M):
+    return (M + 15) // 16 * 16
 
 
 def gemm_wgrad(X, Y, out=None, accumulate=False):

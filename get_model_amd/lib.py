@@ -23,6 +23,7 @@ _SIGNATURES = {
     "getmi_qkv_bias": (_i, [_vp, _vp, _vp, _i, _vp]),
     "getmi_gemm_tn": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp,
                            _sz, _i, _vp]),
+    "getmi_gemm_tn_blocked_ok": (_i, [_i, _i, _i]),
     "getmi_gemm_tn_workspace_bytes": (_sz, [_i, _i]),
     "getmi_gemm_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "getmi_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

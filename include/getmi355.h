@@ -59,7 +59,14 @@ int getmi_gemm_tn(int epi, const void* A, const void* B, int M, int N, int K, in
                   void* stream);
 /* rowscale with epilogue 6: both outputs are multiplied by rowscale[row/rows_per_sample] (the DropPath factor of
  * transformer.py:248 folded into the saved activations, so that no scaled copy of the gradient is needed in backward).
- * flags bit 0 with epilogue 2: the A operand already carries that factor: out0 = resid + acc + rowscale*bias. */
+ * flags bit 0 with epilogue 2: the A operand already carries that factor: out0 = resid + acc + rowscale*bias.
+ * flags bit 1 with epilogue 6 (out0) and 7 (aux): that tensor is in the BLOCKED layout, a private hand-over format between
+ * the two epilogues (the forward of fc1 writes gelu'(u), only the backward of fc2 reads it): for row block rb = row/16
+ * and column block cb = col/64 the 2-KiB block ((rb*(N/64) + cb)) holds [p][lane][8 bf16] with lane = 16*c + r and the
+ * eight values = columns 64cb + 32p + 4c .. +3 and 64cb + 32p + 16 + 4c .. +3 of row 16rb + r -- the MFMA accumulator
+ * layout, so it is stored and re-loaded as whole 1-KiB pieces without the LDS transposition of the row-major form.  The
+ * buffer holds ceil(M/16)*16 rows of N; ldo / ldaux must equal N.  Allowed only where getmi_gemm_tn_blocked_ok says so. */
+int getmi_gemm_tn_blocked_ok(int M, int N, int K);
 /* DGELU / DMUL only: dbias[N] (optional) = column sums of out0 before rounding = bias gradient of the Linear whose
  * pre-activation (or its GELU derivative) is `aux` (fc1.bias); needs workspace of getmi_gemm_tn_workspace_bytes(M, N). */
 size_t getmi_gemm_tn_workspace_bytes(int M, int N);

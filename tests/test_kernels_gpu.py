@@ -552,3 +552,42 @@ def test_layernorm_bwd_bias_sums_without_the_scaled_copy(K):
                                           dx_dtype=torch.bfloat16)
     assert dz2 is dx2
     close(db2, dx2.float().sum(0), 2e-3, 0.5, "ln.dbias(alias)")      # (sums are taken before the bf16 rounding of dx)
+
+
+def _deblock(ub, M, N):
+    """Row-major view of a tensor in the blocked hand-over layout of getmi355.h (flags bit 1 of getmi_gemm_tn)."""
+    nrb, ncb = (M + 15) // 16, N // 64
+    v = ub.view(nrb, ncb, 2, 4, 16, 2, 4)                    # [rb][cb][p][c][r][which piece of the pair][4 columns]
+    # column = 64cb + 32p + 16*piece + 4c + j, row = 16rb + r
+    rm = v.permute(0, 4, 1, 2, 5, 3, 6).reshape(nrb * 16, N)  # [rb][r][cb][p][piece][c][j]
+    return rm[:M]
+
+
+@pytest.mark.parametrize("M,N,Kd,T", [(2060, 512, 128, 103), (4020, 3072, 768, 201), (51456, 768, 256, 201)])
+def test_blocked_handover_of_the_gelu_derivative(K, M, N, Kd, T):
+    """flags bit 1: epilogue 6 writes gelu'(u) in the blocked layout and epilogue 7 reads it back -- bit for bit the
+    row-major results (M not a multiple of 16, 224- and 256-row tiles, with the folded row scale)."""
+    assert K.gemm_tn_blocked_ok(M, N, Kd)
+    assert not K.gemm_tn_blocked_ok(300, N, Kd) and not K.gemm_tn_blocked_ok(M, N + 32, Kd)
+    Bn = M // T
+    sc = ((torch.arange(Bn) % 4 != 2).float() / 0.9).cuda()
+    x = bf(rnd(M, Kd, seed=71))
+    w1 = bf(rnd(N, Kd, scale=0.05, seed=72))
+    b1 = rnd(N, scale=0.1, seed=73)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    g = torch.empty_like(u)
+    K.gemm_tn(K.EPI_BIAS_GELUG, x, w1, u, out1=g, bias=b1, rowscale=sc, rows_per_sample=T)
+    ub = torch.full((K.blocked_rows(M), N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gb = torch.empty_like(g)
+    K.gemm_tn(K.EPI_BIAS_GELUG, x, w1, ub, out1=gb, bias=b1, rowscale=sc, rows_per_sample=T, M=M, blocked=True)
+    assert torch.equal(gb, g)
+    assert torch.equal(_deblock(ub, M, N), u)
+    dy = bf(rnd(M, Kd, seed=74))
+    w2t = bf(rnd(N, Kd, scale=0.05, seed=75))
+    du, db = torch.empty_like(u), torch.empty(N, device="cuda")
+    K.gemm_tn(K.EPI_DMUL, dy, w2t, du, aux=u, dbias=db)
+    du2, db2 = torch.empty_like(u), torch.empty(N, device="cuda")
+    K.gemm_tn(K.EPI_DMUL, dy, w2t, du2, aux=ub, dbias=db2, blocked=True)
+    assert torch.equal(du2, du) and torch.equal(db2, db)
+    with pytest.raises(RuntimeError, match="blocked"):
+        K.gemm_tn(K.EPI_BF16, x, w1, u, blocked=True)
