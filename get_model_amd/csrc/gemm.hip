@@ -556,6 +556,14 @@ __device__ __forceinline__ u32x2 pack4bf_v(float a, float b, float c, float d) {
     return (u32x2){pack2bf(a, b), pack2bf(c, d)};
 }
 
+__device__ __forceinline__ float row16_sum(float v) {      // DPP row_ror:n = 0x120 + n
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x124, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x122, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x121, 0xf, 0xf, true));
+    return v;
+}
+
 template <int EPI, int RB1>
 struct EpiStores {   // buffer-store instructions per wave and output tile (EXACT: used in the counted waits)
     static constexpr int value = ((EpiKind<EPI>::gelu || EPI == EPI_BIAS_RESID) ? 4 : 2) * (4 + TileRows<RB1>::rbmax);
@@ -787,12 +795,10 @@ __device__ __forceinline__ void epilogue_p(const GemmArgs& p, f32x4 (&acc)[8][4]
     if (EpiKind<EPI>::dgelu && p.colsum) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
+            // sum over the 16 lanes (rows) of a DPP row by rotations 8, 4, 2, 1: every lane ends with the total, no LDS
+            // traffic (the ds_bpermute form was 64 LDS operations per wave and tile)
             float4 cc = cs[b];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                cc.x += __shfl_xor(cc.x, o, 64); cc.y += __shfl_xor(cc.y, o, 64);
-                cc.z += __shfl_xor(cc.z, o, 64); cc.w += __shfl_xor(cc.w, o, 64);
-            }
+            cc.x = row16_sum(cc.x); cc.y = row16_sum(cc.y); cc.z = row16_sum(cc.z); cc.w = row16_sum(cc.w);
             const int n = en + b * 16;
             const unsigned off = (r == 0 && n < p.N) ? (unsigned)(((size_t)prow * p.N + n) * 4) : OOB_OFF;
             const f32x4 cv = {cc.x, cc.y, cc.z, cc.w};
