@@ -1151,6 +1151,30 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
     }
 
     STAMP(26);
+    if (wave_active) {
+        // dK / dV rows FIRST (round 3): their stores drain while the bias sums below go through two barriers.  Staged in the Q / dO
+        // ring area (free since the last slice's barrier; 7 x 8 KiB), because the bias sums still read the K image.
+        char* blk = smem + BW_QIMG + wave * 8192;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = db * 32 + 8 * g4 + 4 * h2;
+                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * osc, dk[db][4 * g4 + 1] * osc,
+                                                    dk[db][4 * g4 + 2] * osc, dk[db][4 * g4 + 3] * osc));
+                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4] * sb, dv[db][4 * g4 + 1] * sb, dv[db][4 * g4 + 2] * sb,
+                                                         dv[db][4 * g4 + 3] * sb));
+            }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = stage_row_chunk(blk, row, ch);
+            const int key = key_base + wave * 32 + (row & 31);
+            if (key < T)
+                store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8, v);
+        }
+    }
+    STAMP(27);
     if (p.bias_partial != nullptr) {
         // as in attn_bwd_kernel (no LDS-DMA is in flight any more: plain LDS accesses)
         __syncthreads();
@@ -1209,28 +1233,6 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                 v *= sb;
             }
             p.bias_partial[((size_t)(tid >> 6) * p.B * nkb + (size_t)b * nkb + kbi) * HH + h * HD + d] = v;
-        }
-    }
-    STAMP(27);
-    if (wave_active) {
-        char* blk = smem + BW_KIMG + wave * 8192;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = db * 32 + 8 * g4 + 4 * h2;
-                stage_row_piece(blk, r, d0, pack4bf(dk[db][4 * g4] * osc, dk[db][4 * g4 + 1] * osc,
-                                                    dk[db][4 * g4 + 2] * osc, dk[db][4 * g4 + 3] * osc));
-                stage_row_piece(blk, 32 + r, d0, pack4bf(dv[db][4 * g4] * sb, dv[db][4 * g4 + 1] * sb, dv[db][4 * g4 + 2] * sb,
-                                                         dv[db][4 * g4 + 3] * sb));
-            }
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int row = ps * 8 + (lane >> 3), ch = lane & 7;
-            const uint4 v = stage_row_chunk(blk, row, ch);
-            const int key = key_base + wave * 32 + (row & 31);
-            if (key < T)
-                store_u4<kNtAttn>(p.dqkv + ((size_t)b * T + key) * rs + (size_t)(1 + (row >> 5)) * HH + h * HD + ch * 8, v);
         }
     }
     STAMP(28);
