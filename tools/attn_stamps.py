@@ -4,7 +4,7 @@ prints the median cycles per phase for a few waves.  The product library is not 
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "get_model_amd", "build", "libgetmi355_stamps.so")
+out = os.environ.get("GETMI_STAMPS_LIB", os.path.join(ROOT, "get_model_amd", "build", "libgetmi355_stamps.so"))
 
 
 def build():
