@@ -124,8 +124,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnFwdArgs p) {
             const int chunk = (lane & 7) ^ swz128(row);
             const int key = min(c * 64 + row, T - 1);
             const bf16_t* src = base + (size_t)key * rs + chunk * 8;
-            glds16(src + H * HD, kb + I * 1024);
-            glds16(src + 2 * H * HD, vb + I * 1024);
+            glds16_attn(src + H * HD, kb + I * 1024);
+            glds16_attn(src + 2 * H * HD, vb + I * 1024);
         }
     };
 
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
             const int row = I * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ swz128(row);
             const int key = min(key_base + row, T - 1);
-            glds16(base + (size_t)key * rs + H * HD + chunk * 8, smem + BW_KIMG + I * 1024);
+            glds16_attn(base + (size_t)key * rs + H * HD + chunk * 8, smem + BW_KIMG + I * 1024);
         }
     }
     // ---- V fragments of this wave's 32 keys (second operand of dP = dO.V^T): V[key r][16kk + 8h2 ..] ----
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                 const int q = min(qc + row, T - 1);
                 const bf16_t* src = (wave < 4) ? (base + (size_t)q * rs + chunk * 8)
                                                : (dobase + (size_t)q * (H * HD) + chunk * 8);
-                glds16(src, smem + (wave < 4 ? BW_QIMG : BW_DOIMG) + II * 1024);
+                glds16_attn(src, smem + (wave < 4 ? BW_QIMG : BW_DOIMG) + II * 1024);
             }
         }
         // ---- lse' = lse / scale (+inf past T -> P = 0) and delta = rowsum(dO * O): two threads per query ----
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
             const int row = I * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ swz128(row);
             const int key = min(key_base + row, T - 1);
-            glds16(base + (size_t)key * rs + HH + chunk * 8, smem + BW_KIMG + I * 1024);
+            glds16_attn(base + (size_t)key * rs + HH + chunk * 8, smem + BW_KIMG + I * 1024);
         }
     }
     STAMP(1);
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
                     if (a < n_arr) {
                         char* dst = smem + (a == 0 ? BW_QIMG + (X & 7) * 4096 : a == 1 ? BW_DOIMG + (X & 7) * 4096
                                                                                        : BS_OSTG + slot * 8192 + (a - 2) * 4096);
-                        glds16(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
+                        glds16_attn(w_base[a] + (a == 0 ? oq : oo), dst + part * 1024);
                     }
                 }
             }

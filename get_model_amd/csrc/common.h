@@ -38,17 +38,26 @@ __device__ __forceinline__ uint2 pack4bf(float a, float b, float c, float d) {
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, GETMI_GLDS_AUX);
 }
+// ... and of the attention kernels' LDS-DMA loads (every byte is read once per kernel there)
+#ifndef GETMI_GLDS_AUX_ATTN
+#define GETMI_GLDS_AUX_ATTN 2   // nt: 32.77 -> 32.66 ms/step (three interleaved rounds, one box); sc1 (16): no change
+#endif
+__device__ __forceinline__ void glds16_attn(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc), LDS_PTR(lds_wave_base), 16, 0, GETMI_GLDS_AUX_ATTN);
+}
 
 // Streaming ("nt") stores / loads for data the storing kernel does not read again: the line is not kept in the XCD's L2
 // ahead of the operands that ARE reused there (measured on the persistent GEMM epilogue: -0.45 ms per C2 step).
 // Elsewhere it LOSES, because the next kernel finds the data on chip when it was stored normally (same A/B, ms per step):
 // GEMM epilogue only 35.01; + LayerNorm loads/stores + attention outputs + wgrad slabs 35.50; without the LayerNorm part
-// 35.32, without the attention part 35.41, without the slab part 35.11.  So these three stay OFF (switches for A/B builds).
+// 35.32, without the attention part 35.41, without the slab part 35.11.  So these three stayed OFF in round 2.
+// Round 3 (bf16 gradient stream, folded DropPath: different neighbours for every tensor), same kind of A/B on one box:
+// attention outputs streamed 33.07 -> 32.86 (ON now); LayerNorm 32.78 -> 32.75 (noise, off); slabs 33.07 -> 33.27 (off).
 #ifndef GETMI_NT_LN
 #define GETMI_NT_LN 0
 #endif
 #ifndef GETMI_NT_ATTN
-#define GETMI_NT_ATTN 0
+#define GETMI_NT_ATTN 1
 #endif
 #ifndef GETMI_NT_SLAB
 #define GETMI_NT_SLAB 0
