@@ -19,6 +19,14 @@
 static constexpr bool kNtAttn = GETMI_NT_ATTN != 0;    // outputs are streamed (see common.h)
 #include <stdlib.h>
 
+#ifndef GETMI_ATTN_V_NT
+#define GETMI_ATTN_V_NT 0     // cache policy of the streamed backward's V loads (asm)
+#endif
+#if GETMI_ATTN_V_NT
+#define ATTN_V_POL " nt"
+#else
+#define ATTN_V_POL ""
+#endif
 #define HD 64
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -997,8 +1005,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         u32x4_t vraw[4];
         {
             const bf16_t* vp = base + (size_t)min(mykey, T - 1) * rs + 2 * HH + h2 * 8;
-            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
-                         "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96\n\t"
+            asm volatile("global_load_dwordx4 %0, %4, off" ATTN_V_POL "\n\tglobal_load_dwordx4 %1, %4, off offset:32" ATTN_V_POL "\n\t"
+                         "global_load_dwordx4 %2, %4, off offset:64" ATTN_V_POL "\n\tglobal_load_dwordx4 %3, %4, off offset:96" ATTN_V_POL "\n\t"
                          "s_waitcnt vmcnt(0)"
                          : "=&v"(vraw[0]), "=&v"(vraw[1]), "=&v"(vraw[2]), "=&v"(vraw[3])
                          : "v"(vp)

@@ -11,6 +11,10 @@
 #include "common.h"
 #include <stdlib.h>
 static constexpr bool kNtLn = GETMI_NT_LN != 0;    // activations are streamed: read once, written once
+#ifndef GETMI_NT_LN_BWD_LOADS
+#define GETMI_NT_LN_BWD_LOADS GETMI_NT_LN      // the backward's three input streams alone (their last use in the step)
+#endif
+static constexpr bool kNtLnBwdLd = GETMI_NT_LN_BWD_LOADS != 0;
 
 template <int NV>  // D = NV * 256
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -89,11 +93,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         nrs = rstd[r];
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            nx[v] = load_f4<kNtLn>(x + (size_t)r * D + (v * 64 + lane) * 4);
-            nd[v] = load_u2<kNtLn>(dy + (size_t)r * D + (v * 64 + lane) * 4);
+            nx[v] = load_f4<kNtLnBwdLd>(x + (size_t)r * D + (v * 64 + lane) * 4);
+            nd[v] = load_u2<kNtLnBwdLd>(dy + (size_t)r * D + (v * 64 + lane) * 4);
             if (dres_) {
-                if constexpr (RB) nrb[v] = load_u2<kNtLn>(dresb + (size_t)r * D + (v * 64 + lane) * 4);
-                else nr[v] = load_f4<kNtLn>(dres + (size_t)r * D + (v * 64 + lane) * 4);
+                if constexpr (RB) nrb[v] = load_u2<kNtLnBwdLd>(dresb + (size_t)r * D + (v * 64 + lane) * 4);
+                else nr[v] = load_f4<kNtLnBwdLd>(dres + (size_t)r * D + (v * 64 + lane) * 4);
             }
         }
     };

@@ -11,6 +11,10 @@
 //              (the transposed one staged through LDS so both are written in full 128-byte rows).
 // Per-group hyper-parameters travel by value in the kernel arguments (<= 64 groups per launch).
 #include "common.h"
+#ifndef GETMI_NT_ADAM
+#define GETMI_NT_ADAM 0      // stream (nt) the optimizer state and the gradient: each is touched once per step
+#endif
+static constexpr bool kNtAdam = GETMI_NT_ADAM != 0;
 
 struct AdamGroup {   // mirrors getmi_adamw_group (include/getmi355.h)
     float lr, weight_decay, beta1, beta2, eps, step_size, inv_sqrt_bc2, pad;
@@ -52,15 +56,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamJob* __restrict__ 
             const int e = (it * 256 + tid) * 4;
             if (e + 3 < count) {
                 const float4 p = *reinterpret_cast<const float4*>(j.p + start + e);
-                const float4 g = *reinterpret_cast<const float4*>(j.g + start + e);
-                float4 m = *reinterpret_cast<const float4*>(j.m + start + e);
-                float4 v = *reinterpret_cast<const float4*>(j.v + start + e);
+                const float4 g = load_f4<kNtAdam>(j.g + start + e);
+                float4 m = load_f4<kNtAdam>(j.m + start + e);
+                float4 v = load_f4<kNtAdam>(j.v + start + e);
                 float4 o;
                 o.x = adam_one(p.x, g.x, m.x, v.x, h); o.y = adam_one(p.y, g.y, m.y, v.y, h);
                 o.z = adam_one(p.z, g.z, m.z, v.z, h); o.w = adam_one(p.w, g.w, m.w, v.w, h);
                 *reinterpret_cast<float4*>(j.p + start + e) = o;
-                *reinterpret_cast<float4*>(j.m + start + e) = m;
-                *reinterpret_cast<float4*>(j.v + start + e) = v;
+                store_f4<kNtAdam>(j.m + start + e, m);
+                store_f4<kNtAdam>(j.v + start + e, v);
                 if (j.wn) *reinterpret_cast<uint2*>(j.wn + start + e) = pack4bf(o.x, o.y, o.z, o.w);
             } else {
                 for (int k = e; k < count && k < e + 4; ++k) {      // ragged tail of a tensor
@@ -82,15 +86,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamJob* __restrict__ 
         const int r = tr + it * 16;
         const size_t off = (size_t)(r0 + r) * cols + c0 + tc;
         const float4 p = *reinterpret_cast<const float4*>(j.p + off);
-        const float4 g = *reinterpret_cast<const float4*>(j.g + off);
-        float4 m = *reinterpret_cast<const float4*>(j.m + off);
-        float4 v = *reinterpret_cast<const float4*>(j.v + off);
+        const float4 g = load_f4<kNtAdam>(j.g + off);
+        float4 m = load_f4<kNtAdam>(j.m + off);
+        float4 v = load_f4<kNtAdam>(j.v + off);
         float4 o;
         o.x = adam_one(p.x, g.x, m.x, v.x, h); o.y = adam_one(p.y, g.y, m.y, v.y, h);
         o.z = adam_one(p.z, g.z, m.z, v.z, h); o.w = adam_one(p.w, g.w, m.w, v.w, h);
         *reinterpret_cast<float4*>(j.p + off) = o;
-        *reinterpret_cast<float4*>(j.m + off) = m;
-        *reinterpret_cast<float4*>(j.v + off) = v;
+        store_f4<kNtAdam>(j.m + off, m);
+        store_f4<kNtAdam>(j.v + off, v);
         const uint2 q = pack4bf(o.x, o.y, o.z, o.w);
         if (j.wn) *reinterpret_cast<uint2*>(j.wn + off) = q;
         tile[r][tc] = (bf16_t)(q.x & 0xffff); tile[r][tc + 1] = (bf16_t)(q.x >> 16);
