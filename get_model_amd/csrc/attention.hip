@@ -19,6 +19,10 @@
 static constexpr bool kNtAttn = GETMI_NT_ATTN != 0;    // outputs are streamed (see common.h)
 #include <stdlib.h>
 
+#ifndef GETMI_NT_ATTN_DQ
+#define GETMI_NT_ATTN_DQ 0    // the dQ tiles leave as 32-byte pieces (four waves share a 128-byte row): streamed they reach HBM
+                              // as partial writes (WRITE_SIZE 239 -> 319 MB per launch); cached 32.86 -> 32.69 ms/step (4 rounds)
+#endif
 #ifndef GETMI_ATTN_V_NT
 #define GETMI_ATTN_V_NT 0     // cache policy of the streamed backward's V loads (asm)
 #endif
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(AttnBwdArgs p) {
                 const int d0 = dblk * 16 + (lane >> 4) * 4;
                 if (q < T) {
                     if (p.dq_acc == nullptr) {
-                        store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
+                        store_u2<kNtAttn && (GETMI_NT_ATTN_DQ != 0)>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
                     } else {
                         // long context: this key block's partial dQ goes to its own fp32 slab (plain 16-byte
                         // stores; fp32 atomics measured 2.5 ms per call at T = 2001), summed by attn_dq_convert
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnBwdArgs p) {
         const int d0 = dblk * 16 + (ln >> 4) * 4;
         if (q < T) {
             if (p.dq_acc == nullptr)
-                store_u2<kNtAttn>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
+                store_u2<kNtAttn && (GETMI_NT_ATTN_DQ != 0)>(p.dqkv + ((size_t)b * T + q) * rs + h * HD + d0, pack4bf(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
             else      // several key blocks: this block's partial dQ goes to its own fp32 slab, summed by attn_dq_convert
                 store_f4<kNtAttn>(p.dq_acc + ((size_t)kbi * p.B * T + (size_t)b * T + q) * HH + h * HD + d0, make_float4(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc));
         }
