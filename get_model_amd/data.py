@@ -199,21 +199,39 @@ class RegionBatchProducer:
         self.shuffle, self.seed, self.rank, self.world = shuffle, seed, rank, world
         self.N = dataset.num_region_per_sample
         self.epoch = 0
-        self.tables = {}
-        self.ct_id = {ct: i for i, ct in enumerate(dataset.region_motifs)}
+        # ONE table for all cell types (rows of cell type c start at row0[c]): [motif columns | aTPM], expression pair and
+        # TSS flag per peak.  A batch -- whatever mix of cell types its windows come from -- is then one row gather per
+        # output (the first version gathered per cell type and scattered by batch position: 0.7-1.6 ms per step in the
+        # training loop against 0.1 ms now; tools/ab_producer.sh).
+        full, exp, tss, row0, r0 = [], [], [], {}, 0
+        tss_like = next((rm.tss for rm in dataset.region_motifs.values() if rm.has_expression), None)
         for ct, rm in dataset.region_motifs.items():
             raw = torch.from_numpy(np.ascontiguousarray(rm.data)).to(self.device)
             if rm.normalize:                                   # normalised on the device, as normalized_data does
                 table = (raw / (raw.max(dim=0).values * rm.motif_scaler)).clamp_(max=1.0)
             else:
                 table = raw
-            t = {"motif": table, "atpm": torch.from_numpy(np.ascontiguousarray(rm.atpm)).float().to(self.device)}
-            if rm.has_expression:
-                t["exp"] = torch.from_numpy(np.column_stack((rm.expression_positive, rm.expression_negative))
-                                            .astype(np.float32)).to(self.device)
-                t["tss"] = torch.from_numpy(np.ascontiguousarray(rm.tss)).to(self.device)
-            self.tables[ct] = t
+            atpm = torch.from_numpy(np.ascontiguousarray(rm.atpm)).float().to(self.device)
+            full.append(torch.cat([table.float(), atpm[:, None]], dim=1))
+            n = table.shape[0]
+            if tss_like is not None:
+                if rm.has_expression:
+                    exp.append(torch.from_numpy(np.column_stack((rm.expression_positive, rm.expression_negative))
+                                                .astype(np.float32)).to(self.device))
+                    tss.append(torch.from_numpy(np.ascontiguousarray(rm.tss)).to(self.device))
+                else:
+                    exp.append(torch.zeros(n, 2, device=self.device))
+                    tss.append(torch.zeros((n,) + tuple(tss_like.shape[1:]), dtype=torch.from_numpy(tss_like[:1]).dtype,
+                                           device=self.device))
+            row0[ct] = r0
+            r0 += n
+        self.full = torch.cat(full, dim=0).contiguous()
+        self.exp = torch.cat(exp, dim=0) if exp else None
+        self.tss = torch.cat(tss, dim=0) if tss else None
+        self.F = self.full.shape[1] - 1
         self.win = torch.arange(self.N, device=self.device)
+        # first table row of every sample of the dataset
+        self._row_of = np.array([row0[ct] + s for ct, s, _ in dataset.sample_indices], dtype=np.int64)
 
     def __len__(self):
         return (len(self.ds) // self.world) // self.B
@@ -226,36 +244,24 @@ class RegionBatchProducer:
 
     def gather(self, sample_ids):
         """One batch from explicit sample ids (windows of one batch may come from different cell types)."""
-        B, N = len(sample_ids), self.N
-        F = next(iter(self.tables.values()))["motif"].shape[1]
-        out = {"region_motif": torch.empty(B, N, F + 1, device=self.device),
-               "exp_label": torch.zeros(B, N, 2, device=self.device),
-               "atpm": torch.empty(B, N, 1, device=self.device)}
-        by_ct = {}
-        for pos, sid in enumerate(sample_ids):
-            ct, s, _ = self.ds.sample_indices[int(sid)]
-            by_ct.setdefault(ct, ([], []))
-            by_ct[ct][0].append(pos)
-            by_ct[ct][1].append(s)
-        masks = None
-        for ct, (pos, starts) in by_ct.items():
-            t = self.tables[ct]
-            pos = torch.tensor(pos, device=self.device)
-            rows = torch.tensor(starts, device=self.device)[:, None] + self.win[None, :]      # [b, N] table rows
-            atpm = t["atpm"][rows]
-            out["region_motif"][pos, :, :F] = t["motif"][rows]
-            out["region_motif"][pos, :, F] = atpm / atpm.max(dim=1, keepdim=True).values \
-                if self.ds.quantitative_atac else 1.0
-            out["atpm"][pos] = atpm[:, :, None]
-            if "exp" in t:
-                out["exp_label"][pos] = t["exp"][rows]
-                if self.ds.mask_ratio <= 0:
-                    if masks is None:
-                        masks = torch.zeros((B, N) + tuple(t["tss"].shape[1:]), dtype=t["tss"].dtype, device=self.device)
-                    masks[pos] = t["tss"][rows]
+        ids = np.asarray(sample_ids, dtype=np.int64)
+        B, N, F = len(ids), self.N, self.F
+        st = torch.from_numpy(self._row_of[ids]).to(self.device, non_blocking=True)
+        rows = st[:, None] + self.win[None, :]                                            # [B, N] table rows
+        rm = self.full[rows]                                                              # [B, N, F + 1]
+        atpm = rm[:, :, F].clone()
+        if self.ds.quantitative_atac:
+            rm[:, :, F] = atpm / atpm.max(dim=1, keepdim=True).values
+        else:
+            rm[:, :, F] = 1.0
+        out = {"region_motif": rm, "atpm": atpm[:, :, None]}
+        out["exp_label"] = self.exp[rows] if self.exp is not None else torch.zeros(B, N, 2, device=self.device)
         if self.ds.mask_ratio > 0:                              # pretrain: Bernoulli(mask_ratio) per region
-            masks = (torch.rand(B, N, device=self.device) < self.ds.mask_ratio).to(torch.int64)
-        out["mask"] = masks if masks is not None else torch.zeros(B, N, dtype=torch.int64, device=self.device)
+            out["mask"] = (torch.rand(B, N, device=self.device) < self.ds.mask_ratio).to(torch.int64)
+        elif self.tss is not None:
+            out["mask"] = self.tss[rows]
+        else:
+            out["mask"] = torch.zeros(B, N, dtype=torch.int64, device=self.device)
         return out
 
     def __iter__(self):
