@@ -45,6 +45,29 @@ def cases():
     out2, lse2, lo2 = K.attention_fwd(x3, B, T, H, 0.125, want_lo=True)
     yield "attention bwd (O_lo)", lambda: res.__setitem__("c", K.attention_bwd(x3, out2, xD, lse2, B, T, H, 0.125, want_bias=True, out_lo=lo2)), \
         lambda: torch.cat([res["c"][0].float().flatten(), res["c"][1], res["c"][2]])
+    # round 3: the blocked hand-over of gelu'(u), the folded DropPath factors, the bf16-stream LayerNorm backward
+    ub = torch.empty(K.blocked_rows(M), F, dtype=torch.bfloat16, device=dev)
+    yield "fc1 fwd (blocked gelu', row scale)", lambda: K.gemm_tn(K.EPI_BIAS_GELUG, xD, w1, ub, out1=oF2, bias=bF, rowscale=scale,
+                                                                   rows_per_sample=T, M=M, blocked=True), lambda: torch.cat([ub[:M], oF2])
+    K.gemm_tn(K.EPI_BIAS_GELUG, xD, w1, ub, out1=oF2, bias=bF, rowscale=scale, rows_per_sample=T, M=M, blocked=True)
+    ubk = ub.clone()
+    yield "fc2 dgrad (dmul, blocked aux)", lambda: K.gemm_tn(K.EPI_DMUL, xD, w1, oF, aux=ubk, dbias=db, blocked=True), \
+        lambda: torch.cat([oF.float().flatten(), db])
+    yield "fc2 fwd (resid, prescaled)", lambda: K.gemm_tn(K.EPI_BIAS_RESID, xF, w2, oDf, bias=bD, resid=resid, rowscale=scale,
+                                                          rows_per_sample=T, prescaled=True), lambda: oDf
+    drop = scale.clone(); drop[::5] = 0.0
+    out3, lse3, lo3 = K.attention_fwd(x3, B, T, H, 0.125, want_lo=True, sample_scale=drop)
+    yield "attention fwd (sample scale)", lambda: res.__setitem__("e", K.attention_fwd(x3, B, T, H, 0.125, want_lo=True, sample_scale=drop)), \
+        lambda: torch.cat([res["e"][0].float().flatten(), res["e"][1].flatten(), res["e"][2].float().flatten()])
+    yield "attention bwd (sample scale)", lambda: res.__setitem__("f", K.attention_bwd(x3, out3, xD, lse3, B, T, H, 0.125, want_bias=True,
+                                                                                       out_lo=lo3, sample_scale=drop)), \
+        lambda: torch.cat([res["f"][0].float().flatten(), res["f"][1], res["f"][2]])
+    xf32 = rf(M, D); gam = rf(D)
+    _, mean, rstd = K.layernorm_fwd(xf32, gam, bD)
+    yield "layernorm bwd (bf16 stream)", lambda: res.__setitem__("g", K.layernorm_bwd(xD, xf32, mean, rstd, gam, dres=oD, rowscale=scale,
+                                                                                      rows_per_sample=T, want_dz=False, want_dbias=True,
+                                                                                      dx_dtype=torch.bfloat16)), \
+        lambda: torch.cat([res["g"][0].float().flatten(), res["g"][2], res["g"][3], res["g"][4]])
     BL, TL = 4, 2001
     xl, dl = rb(BL * TL, 3 * H * 64), rb(BL * TL, H * 64)
     outl, lsel, lol = K.attention_fwd(xl, BL, TL, H, 0.125, want_lo=True)
